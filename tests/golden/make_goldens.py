@@ -1,0 +1,193 @@
+"""Generates tests/golden/*.npz|json from the reference's own pure-Python /
+pure-numpy functions, run in the build container (the reference never travels).
+
+What is and is not exercised:
+  * fen_generator.py has no imports: imported and called directly.
+  * piece_detector.py, grid_extractor.py, board_detection.py and
+    change_detector.py start with `import cv2`, which is not installed here.
+    An EMPTY module object (no attributes at all) is registered under that name
+    so the import statement succeeds; only functions that never touch cv2 are
+    called (_detect_center_vs_border, _analyze_radial_symmetry,
+    _update_history/_get_stable_detection, split_board, reorder,
+    classify_hand_pattern).  cv2 stays functionally absent: any call into it
+    would raise AttributeError.  No OpenCV arithmetic is pinned by these files.
+  * noise_handler.py imports cleanly (no third-party deps).
+
+Run:  python tests/golden/make_goldens.py   (needs /root/reference)
+"""
+import contextlib
+import io
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+
+if "cv2" not in sys.modules:
+    sys.modules["cv2"] = types.ModuleType("cv2")  # empty: import gate only
+
+_cwd = os.getcwd()
+os.chdir("/tmp")  # keep the reference from finding its JSON settings in cwd
+with contextlib.redirect_stdout(io.StringIO()):
+    import fen_generator
+    import piece_detector
+    import grid_extractor
+    import board_detection
+    import change_detector
+os.chdir(_cwd)
+
+from chessboard_vision_amd import synth  # scene script (ours)
+
+
+def gold_fen():
+    out = {"get_chess_square": [], "generate_fen": [], "map_detections": []}
+    for bs in (620, 616, 800):
+        for (x, y) in [(0, 0), (77, 77), (619, 619), (300, 10), (10, 300), (620, 5), (5, 620), (799, 799), (-1, 4), (154, 539)]:
+            name, (gx, gy) = fen_generator.get_chess_square(x, y, bs)
+            out["get_chess_square"].append({"x": x, "y": y, "board_size": bs, "name": name, "grid": [gx, gy]})
+    for plies in range(len(synth.SCRIPT) + 1):
+        pos = synth.position_after(plies)
+        board_map = {(f, 7 - r): {"fen": ch} for (f, r), ch in pos.items()}
+        turn = "w" if plies % 2 == 0 else "b"
+        fen = fen_generator.generate_fen(board_map, turn)
+        out["generate_fen"].append({"plies": plies, "turn": turn,
+                                    "board_map": [[f, gy, d["fen"]] for (f, gy), d in sorted(board_map.items())],
+                                    "fen": fen})
+    out["generate_fen"].append({"plies": -1, "turn": "w", "board_map": [], "fen": fen_generator.generate_fen({}, "w")})
+    dets = [
+        {"center": (40, 40), "class": "black-rook", "conf": 0.9},
+        {"center": (50, 30), "class": "black-queen", "conf": 0.95},
+        {"center": (45, 45), "class": "white-pawn", "conf": 0.5},
+        {"center": (600, 600), "class": "white-rook", "conf": 0.7},
+        {"center": (700, 10), "class": "white-king", "conf": 0.99},
+        {"center": (310, 310), "class": "unknown-thing", "conf": 0.3},
+    ]
+    bm = fen_generator.map_detections_to_board(dets, 620)
+    out["map_detections"].append({"detections": [{"center": list(d["center"]), "class": d["class"], "conf": d["conf"]} for d in dets],
+                                  "board_size": 620,
+                                  "board_map": [[gx, gy, v["fen"], v["conf"], v["class"]] for (gx, gy), v in sorted(bm.items())],
+                                  "fen": fen_generator.generate_fen(bm)})
+    with open(os.path.join(OUT, "fen_generator.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
+def gold_piece_numpy():
+    pd = piece_detector.PieceDetector.__new__(piece_detector.PieceDetector)
+    pd.history_size = 5
+    pd.min_presence = 0.6
+    pd.detection_history = {}
+    rng = np.random.default_rng(20240611)
+    grays, cvb, sym = [], [], []
+    shapes = [(77, 77), (77, 77), (77, 77), (80, 79), (76, 78), (50, 50), (78, 77), (77, 77), (77, 77), (64, 48)]
+    for i, (h, w) in enumerate(shapes):
+        yy, xx = np.mgrid[:h, :w]
+        base = rng.integers(0, 256)
+        img = np.full((h, w), base, np.int32)
+        if i % 3 != 2:  # disc of random radius/colour
+            r = rng.integers(8, min(h, w) // 2)
+            col = rng.integers(0, 256)
+            img[(xx - w // 2 - rng.integers(-3, 4)) ** 2 + (yy - h // 2 - rng.integers(-3, 4)) ** 2 <= r * r] = col
+        img = img + rng.integers(-6, 7, size=(h, w))
+        if i == 7:
+            img = rng.integers(0, 256, size=(h, w))
+        if i == 8:
+            img = np.full((h, w), 128)
+        g = np.clip(img, 0, 255).astype(np.uint8)
+        d, cm, bm = pd._detect_center_vs_border(g)
+        s = pd._analyze_radial_symmetry(g)
+        grays.append(g)
+        cvb.append([float(d), float(cm), float(bm)])
+        sym.append(float(s))
+    arrs = {"gray_%d" % i: g for i, g in enumerate(grays)}
+    arrs["center_vs_border"] = np.array(cvb, np.float64)
+    arrs["radial_symmetry"] = np.array(sym, np.float64)
+    np.savez_compressed(os.path.join(OUT, "piece_numpy.npz"), **arrs)
+
+    # temporal smoothing: _update_history/_get_stable_detection (piece_detector.py:99-122)
+    seqs = []
+    for seed in range(6):
+        r = np.random.default_rng(seed)
+        seq = [bool(v) for v in r.integers(0, 2, size=14)]
+        pd.detection_history = {}
+        stable = []
+        for v in seq:
+            pd._update_history((1, 1), v)
+            stable.append(bool(pd._get_stable_detection((1, 1))))
+        seqs.append({"raw": seq, "stable": stable})
+    pd.detection_history = {}
+    seqs.append({"raw": [], "stable": [], "no_history": bool(pd._get_stable_detection((0, 0)))})
+    with open(os.path.join(OUT, "piece_history.json"), "w") as f:
+        json.dump(seqs, f)
+
+
+def gold_grid():
+    out = {}
+    img = np.zeros((620, 620, 3), np.uint8)
+    base = img.ctypes.data
+
+    def rois(sq):
+        res = []
+        for (f, r), v in sorted(sq.items()):
+            off = v.ctypes.data - base
+            y0, rem = divmod(off, img.strides[0])
+            x0 = rem // 3
+            res.append([f, r, int(x0), int(y0), int(v.shape[1]), int(v.shape[0]), list(v.strides)])
+        return res
+
+    out["linear_620"] = rois(grid_extractor.GridExtractor().split_board(img))
+    sg = grid_extractor.SmartGridExtractor()
+    out["smart_unset_620"] = rois(sg.split_board(img))
+    sg.grid_lines_x = list(synth.CALIB_GRID_X)
+    sg.grid_lines_y = list(synth.CALIB_GRID_Y)
+    out["smart_calib_620"] = rois(sg.split_board(img))
+    sg.grid_lines_x = [0, 79, 157, 157, 310, 386, 464, 541, 620]  # degenerate column skipped (grid_extractor.py:149-150)
+    out["smart_degenerate_620"] = rois(sg.split_board(img))
+    img2 = np.zeros((400, 400, 3), np.uint8)
+    base2 = img2.ctypes.data
+    sq = grid_extractor.GridExtractor().split_board(img2)
+    out["linear_400"] = [[f, r, int((v.ctypes.data - base2) % img2.strides[0] // 3), int((v.ctypes.data - base2) // img2.strides[0]),
+                          int(v.shape[1]), int(v.shape[0])] for (f, r), v in sorted(sq.items())]
+    pts = []
+    for p in ([[556, 112], [1560, 108], [1562, 1024], [550, 1005]], [[1562, 1024], [550, 1005], [556, 112], [1560, 108]],
+              [[10, 10], [100, 12], [8, 90], [95, 99]], [[300, 40], [40, 300], [560, 310], [310, 580]]):
+        a = np.array(p, np.int32)
+        pts.append({"in": p, "out": board_detection.reorder(a).reshape(4, 2).tolist()})
+    out["reorder"] = pts
+    with open(os.path.join(OUT, "grid_and_reorder.json"), "w") as f:
+        json.dump(out, f)
+
+
+def gold_hand_pattern():
+    with contextlib.redirect_stdout(io.StringIO()):
+        cd = change_detector.ChangeDetectorPython.__new__(change_detector.ChangeDetectorPython)
+    cases = []
+    pats = [
+        {},
+        {(1, 1): "PARCIAL"},
+        {(1, 1): "PARCIAL", (1, 3): "PARCIAL"},
+        {(1, 1): "TOTAL", (1, 3): "TOTAL"},
+        {(1, 1): "TOTAL", (1, 3): "LEVE"},
+        {(1, 1): "LEVE", (1, 3): "LEVE", (2, 2): "PARCIAL"},
+        {(0, 0): "LEVE", (1, 3): "LEVE", (2, 2): "PARCIAL", (5, 5): "LEVE"},
+    ]
+    for p in pats:
+        detailed = {k: {"intensity": v, "pct_changed": 10.0, "z_score": 3.0, "is_circular": False, "center_ratio": 1.0} for k, v in p.items()}
+        res = cd.classify_hand_pattern(detailed)
+        cases.append({"in": [[k[0], k[1], v] for k, v in p.items()], "is_hand": res["is_hand"], "is_move": res["is_move"],
+                      "move_candidates": sorted([list(c) for c in res["move_candidates"]])})
+    with open(os.path.join(OUT, "hand_pattern.json"), "w") as f:
+        json.dump(cases, f)
+
+
+if __name__ == "__main__":
+    gold_fen()
+    gold_piece_numpy()
+    gold_grid()
+    gold_hand_pattern()
+    print("goldens written to", OUT)
