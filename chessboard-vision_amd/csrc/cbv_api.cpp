@@ -1,0 +1,1055 @@
+// C-ABI of libcbv_hip.so (include/cbv.h): context, host-buffer stage entry
+// points, per-square detector state and the device-resident batched pipeline.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "cbv_internal.h"
+
+thread_local std::string g_cbv_err;
+
+int cbv_fail(cbv_ctx* ctx, int code, const char* fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_cbv_err = buf;
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+int dev_ensure(cbv_ctx* ctx, DevBuf* b, size_t bytes)
+{
+    if (b->cap >= bytes && b->p) return CBV_OK;
+    if (b->p) {
+        CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(b->p);
+        b->p = nullptr;
+        b->cap = 0;
+    }
+    size_t cap = (bytes + 4095) & ~(size_t)4095;
+    CBV_HIP(ctx, hipMalloc(&b->p, cap));
+    b->cap = cap;
+    return CBV_OK;
+}
+
+void dev_free(DevBuf* b)
+{
+    if (b->p) (void)hipFree(b->p);
+    b->p = nullptr;
+    b->cap = 0;
+}
+
+// ---------------------------------------------------------------------------
+// profiling
+// ---------------------------------------------------------------------------
+static const char* kKernelNames[CBV_K_COUNT] = {
+    "k_color_lab_hist", "k_clahe_lut", "k_clahe_apply", "k_bilateral", "k_sharpen", "k_norm_lut", "k_normalize",
+    "k_warp", "k_squares", "k_gray_blur_hist", "k_otsu", "k_threshold", "k_scan", "k_synth", "k_reset_aux"};
+
+static hipEvent_t prof_get_event(cbv_ctx* ctx)
+{
+    if (!ctx->prof_pool.empty()) {
+        hipEvent_t e = ctx->prof_pool.back();
+        ctx->prof_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+void prof_begin(cbv_ctx* ctx, int kid)
+{
+    if (ctx->prof_kid == -2 || (ctx->prof_kid != -1 && ctx->prof_kid != kid)) return;
+    ProfSlot s;
+    s.kid = kid;
+    s.a = prof_get_event(ctx);
+    s.b = prof_get_event(ctx);
+    (void)hipEventRecord(s.a, ctx->stream);
+    ctx->prof_pending.push_back(s);
+}
+
+void prof_end(cbv_ctx* ctx, int kid)
+{
+    if (ctx->prof_kid == -2 || (ctx->prof_kid != -1 && ctx->prof_kid != kid)) return;
+    if (ctx->prof_pending.empty()) return;
+    (void)hipEventRecord(ctx->prof_pending.back().b, ctx->stream);
+}
+
+static void prof_drain(cbv_ctx* ctx)
+{
+    for (auto& s : ctx->prof_pending) {
+        float ms = 0;
+        if (hipEventSynchronize(s.b) == hipSuccess && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+            ctx->prof_ms[s.kid] += ms;
+            ctx->prof_n[s.kid] += 1;
+        }
+        ctx->prof_pool.push_back(s.a);
+        ctx->prof_pool.push_back(s.b);
+    }
+    ctx->prof_pending.clear();
+}
+
+extern "C" int cbv_profile_enable(cbv_ctx* ctx, int kid)
+{
+    if (!ctx) return CBV_ERR_ARG;
+    prof_drain(ctx);
+    ctx->prof_kid = kid;
+    return CBV_OK;
+}
+
+extern "C" int cbv_profile_read(cbv_ctx* ctx, int kid, double* total_ms, long long* launches)
+{
+    if (!ctx || kid < 0 || kid >= CBV_K_COUNT) return CBV_ERR_ARG;
+    prof_drain(ctx);
+    if (total_ms) *total_ms = ctx->prof_ms[kid];
+    if (launches) *launches = ctx->prof_n[kid];
+    return CBV_OK;
+}
+
+extern "C" int cbv_profile_reset(cbv_ctx* ctx)
+{
+    if (!ctx) return CBV_ERR_ARG;
+    prof_drain(ctx);
+    for (int i = 0; i < CBV_K_COUNT; i++) {
+        ctx->prof_ms[i] = 0;
+        ctx->prof_n[i] = 0;
+    }
+    return CBV_OK;
+}
+
+extern "C" const char* cbv_kernel_name(int kid) { return (kid >= 0 && kid < CBV_K_COUNT) ? kKernelNames[kid] : ""; }
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+extern "C" int cbv_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" const char* cbv_last_error(const cbv_ctx* ctx) { return ctx ? ctx->err.c_str() : g_cbv_err.c_str(); }
+extern "C" const char* cbv_device_name(const cbv_ctx* ctx) { return ctx ? ctx->devname : ""; }
+
+extern "C" int cbv_ctx_create(int device_id, cbv_ctx** out)
+{
+    if (!out) return cbv_fail(nullptr, CBV_ERR_ARG, "cbv_ctx_create: out is null");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return cbv_fail(nullptr, CBV_ERR_NODEV, "no HIP device available (%s); this library has no CPU fallback",
+                        e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (device_id < 0 || device_id >= n) return cbv_fail(nullptr, CBV_ERR_ARG, "device %d out of range (%d devices)", device_id, n);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return cbv_fail(nullptr, CBV_ERR_HIP, "hipGetDeviceProperties failed");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return cbv_fail(nullptr, CBV_ERR_NODEV, "device %d is %s; libcbv_hip.so carries gfx950 (MI355X) code only", device_id,
+                        prop.gcnArchName);
+    cbv_ctx* ctx = new cbv_ctx();
+    ctx->device = device_id;
+    ctx->num_cus = prop.multiProcessorCount;
+    snprintf(ctx->devname, sizeof(ctx->devname), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+#define CK(call)                                                                                       \
+    do {                                                                                               \
+        hipError_t e2 = (call);                                                                        \
+        if (e2 != hipSuccess) {                                                                        \
+            int rc = cbv_fail(nullptr, CBV_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e2));    \
+            delete ctx;                                                                                \
+            return rc;                                                                                 \
+        }                                                                                              \
+    } while (0)
+    CK(hipSetDevice(device_id));
+    CK(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    ctx->stream = ctx->own_stream;
+    CK(hipMalloc((void**)&ctx->tabs, sizeof(StaticTabs)));
+    CK(hipMalloc((void**)&ctx->ptabs, sizeof(ProfileTabs)));
+    CK(hipMalloc((void**)&ctx->btabs, sizeof(BilateralTabs)));
+    {
+        StaticTabs* st = new StaticTabs();
+        build_static_tabs(st);
+        hipError_t up = hipMemcpy(ctx->tabs, st, sizeof(StaticTabs), hipMemcpyHostToDevice);
+        delete st;
+        CK(up);
+        cbv_color_profile none;
+        memset(&none, 0, sizeof(none));
+        ProfileTabs pt;
+        build_profile_tabs(&none, &pt);
+        CK(hipMemcpy(ctx->ptabs, &pt, sizeof(pt), hipMemcpyHostToDevice));
+        ctx->ptabs_key = none;
+        ctx->ptabs_valid = true;
+    }
+#undef CK
+    *out = ctx;
+    return CBV_OK;
+}
+
+extern "C" void cbv_ctx_destroy(cbv_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    prof_drain(ctx);
+    for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
+    dev_free(&ctx->in);
+    dev_free(&ctx->a);
+    dev_free(&ctx->b);
+    dev_free(&ctx->c);
+    dev_free(&ctx->small);
+    if (ctx->tabs) (void)hipFree(ctx->tabs);
+    if (ctx->ptabs) (void)hipFree(ctx->ptabs);
+    if (ctx->btabs) (void)hipFree(ctx->btabs);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+extern "C" int cbv_ctx_set_stream(cbv_ctx* ctx, void* hip_stream)
+{
+    if (!ctx) return CBV_ERR_ARG;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return CBV_OK;
+}
+
+extern "C" int cbv_ctx_synchronize(cbv_ctx* ctx)
+{
+    if (!ctx) return CBV_ERR_ARG;
+    CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CBV_OK;
+}
+
+int ctx_set_profile(cbv_ctx* ctx, const cbv_color_profile* p)
+{
+    cbv_color_profile key;
+    memset(&key, 0, sizeof(key));
+    if (p) {
+        key.hue_shift = p->hue_shift;
+        key.sat_scale = p->sat_scale;
+        key.val_scale = p->val_scale;
+        key.contrast = p->contrast;
+        key.brightness = p->brightness;
+        key.radical_mode = p->radical_mode ? 1 : 0;
+        key.target_hue = p->target_hue;
+        key.hue_window = p->hue_window;
+        key.enabled = p->enabled ? 1 : 0;
+    }
+    if (ctx->ptabs_valid && memcmp(&key, &ctx->ptabs_key, sizeof(key)) == 0) return CBV_OK;
+    ProfileTabs pt;
+    build_profile_tabs(&key, &pt);
+    CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CBV_HIP(ctx, hipMemcpy(ctx->ptabs, &pt, sizeof(pt), hipMemcpyHostToDevice));
+    ctx->ptabs_key = key;
+    ctx->ptabs_valid = true;
+    return CBV_OK;
+}
+
+int ctx_set_bilateral(cbv_ctx* ctx, int d, double sc, double ss)
+{
+    if (ctx->b_d == d && ctx->b_sc == sc && ctx->b_ss == ss) return CBV_OK;
+    if (build_bilateral_tabs(d, sc, ss, &ctx->btabs_host) != 0)
+        return cbv_fail(ctx, CBV_ERR_UNSUPPORTED, "bilateral d=%d not supported (radius <= 4)", d);
+    if (ctx->btabs_host.radius > 4) return cbv_fail(ctx, CBV_ERR_UNSUPPORTED, "bilateral d=%d not supported (radius <= 4)", d);
+    CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CBV_HIP(ctx, hipMemcpy(ctx->btabs, &ctx->btabs_host, sizeof(BilateralTabs), hipMemcpyHostToDevice));
+    ctx->b_d = d;
+    ctx->b_sc = sc;
+    ctx->b_ss = ss;
+    return CBV_OK;
+}
+
+// ---------------------------------------------------------------------------
+// host-buffer stage entry points
+// ---------------------------------------------------------------------------
+static int check_img(cbv_ctx* ctx, const void* p, int w, int h, int stride, int cn, const char* what)
+{
+    if (!ctx) return cbv_fail(nullptr, CBV_ERR_ARG, "%s: ctx is null", what);
+    if (!p || w <= 0 || h <= 0 || stride < w * cn) return cbv_fail(ctx, CBV_ERR_ARG, "%s: bad image arguments (w=%d h=%d stride=%d)", what, w, h, stride);
+    if ((size_t)w * h > (size_t)1 << 28) return cbv_fail(ctx, CBV_ERR_ARG, "%s: image too large", what);
+    return CBV_OK;
+}
+
+static Geom tight_geom(int w, int h)
+{
+    Geom g;
+    g.w = w;
+    g.h = h;
+    g.stride = w * 3;
+    g.frame_stride = ((size_t)w * 3 * h + 255) & ~(size_t)255;
+    return g;
+}
+
+static int upload(cbv_ctx* ctx, DevBuf* dst, const u8* src, int wbytes, int h, int stride)
+{
+    int rc = dev_ensure(ctx, dst, (size_t)wbytes * h + 256);
+    if (rc) return rc;
+    CBV_HIP(ctx, hipMemcpy2DAsync(dst->p, wbytes, src, stride, wbytes, h, hipMemcpyHostToDevice, ctx->stream));
+    return CBV_OK;
+}
+
+static int download(cbv_ctx* ctx, const void* src, u8* dst, int wbytes, int h, int stride)
+{
+    CBV_HIP(ctx, hipMemcpy2DAsync(dst, stride, src, wbytes, wbytes, h, hipMemcpyDeviceToHost, ctx->stream));
+    CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CBV_OK;
+}
+
+struct SmallLayout {
+    u32* aux;
+    u8* luts;
+    u8* norm_lut;
+};
+
+static int small_layout(cbv_ctx* ctx, DevBuf* buf, int tiles, int batch, SmallLayout* L)
+{
+    size_t aux_b = aux_words(tiles) * 4 * batch;
+    aux_b = (aux_b + 255) & ~(size_t)255;
+    size_t lut_b = ((size_t)tiles * 256 * batch + 255) & ~(size_t)255;
+    size_t nl_b = (size_t)256 * batch;
+    int rc = dev_ensure(ctx, buf, aux_b + lut_b + nl_b);
+    if (rc) return rc;
+    L->aux = (u32*)buf->p;
+    L->luts = (u8*)buf->p + aux_b;
+    L->norm_lut = (u8*)buf->p + aux_b + lut_b;
+    return CBV_OK;
+}
+
+#define RC(x)             \
+    do {                  \
+        int rc__ = (x);   \
+        if (rc__) return rc__; \
+    } while (0)
+
+extern "C" int cbv_apply_color_profile(cbv_ctx* ctx, const uint8_t* bgr, int w, int h, int stride,
+                                       const cbv_color_profile* profile, uint8_t* out, int out_stride)
+{
+    RC(check_img(ctx, bgr, w, h, stride, 3, "cbv_apply_color_profile"));
+    if (!out || !profile) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_apply_color_profile: null argument");
+    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    RC(upload(ctx, &ctx->in, bgr, w * 3, h, stride));
+    if (!profile->enabled) return download(ctx, ctx->in.p, out, w * 3, h, out_stride); // `{}` profile: identity
+    RC(ctx_set_profile(ctx, profile));
+    Geom g = tight_geom(w, h);
+    RC(dev_ensure(ctx, &ctx->a, g.frame_stride));
+    SmallLayout S;
+    RC(small_layout(ctx, &ctx->small, 1, 1, &S));
+    ClaheGeom cg = clahe_geom(w, h, 0.0, 1, 1); // one tile = whole image; only used for the traversal
+    RC(launch_color_lab_hist(ctx, (const u8*)ctx->in.p, (u8*)ctx->a.p, S.aux, g, cg, 1, 1, 0));
+    return download(ctx, ctx->a.p, out, w * 3, h, out_stride);
+}
+
+extern "C" int cbv_correct_lighting(cbv_ctx* ctx, const uint8_t* bgr, int w, int h, int stride, double clip_limit,
+                                    int tiles_x, int tiles_y, uint8_t* out, int out_stride)
+{
+    RC(check_img(ctx, bgr, w, h, stride, 3, "cbv_correct_lighting"));
+    if (!out || tiles_x <= 0 || tiles_y <= 0 || tiles_x > 64 || tiles_y > 64) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_correct_lighting: bad arguments");
+    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    RC(upload(ctx, &ctx->in, bgr, w * 3, h, stride));
+    Geom g = tight_geom(w, h);
+    RC(dev_ensure(ctx, &ctx->a, g.frame_stride));
+    RC(dev_ensure(ctx, &ctx->b, g.frame_stride));
+    ClaheGeom cg = clahe_geom(w, h, clip_limit, tiles_x, tiles_y);
+    int tiles = tiles_x * tiles_y;
+    SmallLayout S;
+    RC(small_layout(ctx, &ctx->small, tiles, 1, &S));
+    RC(launch_reset_aux(ctx, S.aux, tiles, 1));
+    RC(launch_color_lab_hist(ctx, (const u8*)ctx->in.p, (u8*)ctx->a.p, S.aux, g, cg, 1, 0, 1));
+    RC(launch_clahe_lut(ctx, S.aux, S.luts, cg, 1));
+    RC(launch_clahe_apply(ctx, (const u8*)ctx->a.p, S.luts, (u8*)ctx->b.p, g, cg, 1));
+    return download(ctx, ctx->b.p, out, w * 3, h, out_stride);
+}
+
+extern "C" int cbv_reduce_noise(cbv_ctx* ctx, const uint8_t* bgr, int w, int h, int stride, int d, double sigma_color,
+                                double sigma_space, uint8_t* out, int out_stride)
+{
+    RC(check_img(ctx, bgr, w, h, stride, 3, "cbv_reduce_noise"));
+    if (!out) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_reduce_noise: out is null");
+    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    RC(ctx_set_bilateral(ctx, d, sigma_color, sigma_space));
+    RC(upload(ctx, &ctx->in, bgr, w * 3, h, stride));
+    Geom g = tight_geom(w, h);
+    RC(dev_ensure(ctx, &ctx->a, g.frame_stride));
+    RC(launch_bilateral(ctx, (const u8*)ctx->in.p, (u8*)ctx->a.p, g, 1));
+    return download(ctx, ctx->a.p, out, w * 3, h, out_stride);
+}
+
+extern "C" int cbv_sharpen(cbv_ctx* ctx, const uint8_t* bgr, int w, int h, int stride, const float* kernel9, uint8_t* out,
+                           int out_stride)
+{
+    RC(check_img(ctx, bgr, w, h, stride, 3, "cbv_sharpen"));
+    if (!out || !kernel9) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_sharpen: null argument");
+    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    RC(upload(ctx, &ctx->in, bgr, w * 3, h, stride));
+    Geom g = tight_geom(w, h);
+    RC(dev_ensure(ctx, &ctx->a, g.frame_stride));
+    SmallLayout S;
+    RC(small_layout(ctx, &ctx->small, 1, 1, &S));
+    RC(launch_reset_aux(ctx, S.aux, 1, 1));
+    RC(launch_sharpen(ctx, (const u8*)ctx->in.p, (u8*)ctx->a.p, S.aux, 1, g, kernel9, 1));
+    return download(ctx, ctx->a.p, out, w * 3, h, out_stride);
+}
+
+int launch_minmax(cbv_ctx* ctx, const u8* src, u32* aux, int tiles, Geom g, int batch);
+
+extern "C" int cbv_normalize_intensity(cbv_ctx* ctx, const uint8_t* bgr, int w, int h, int stride, uint8_t* out,
+                                       int out_stride)
+{
+    RC(check_img(ctx, bgr, w, h, stride, 3, "cbv_normalize_intensity"));
+    if (!out) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_normalize_intensity: out is null");
+    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    RC(upload(ctx, &ctx->in, bgr, w * 3, h, stride));
+    Geom g = tight_geom(w, h);
+    RC(dev_ensure(ctx, &ctx->a, g.frame_stride));
+    SmallLayout S;
+    RC(small_layout(ctx, &ctx->small, 1, 1, &S));
+    RC(launch_reset_aux(ctx, S.aux, 1, 1));
+    RC(launch_minmax(ctx, (const u8*)ctx->in.p, S.aux, 1, g, 1));
+    RC(launch_norm_lut(ctx, S.aux, 1, S.norm_lut, 1));
+    RC(launch_normalize(ctx, (const u8*)ctx->in.p, (u8*)ctx->a.p, S.norm_lut, g, 1));
+    return download(ctx, ctx->a.p, out, w * 3, h, out_stride);
+}
+
+extern "C" int cbv_prepare_analysis(cbv_ctx* ctx, const uint8_t* bgr, int w, int h, int stride, uint8_t* gray,
+                                    int gray_stride, uint8_t* binary, int binary_stride, int* otsu_threshold)
+{
+    RC(check_img(ctx, bgr, w, h, stride, 3, "cbv_prepare_analysis"));
+    if (!gray || !binary) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_prepare_analysis: null output");
+    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    RC(upload(ctx, &ctx->in, bgr, w * 3, h, stride));
+    Geom g = tight_geom(w, h);
+    size_t plane = ((size_t)w * h + 255) & ~(size_t)255;
+    RC(dev_ensure(ctx, &ctx->a, plane * 3));
+    u8* dgray = (u8*)ctx->a.p;
+    u8* dblur = dgray + plane;
+    u8* dbin = dblur + plane;
+    SmallLayout S;
+    RC(small_layout(ctx, &ctx->small, 1, 1, &S));
+    RC(launch_reset_aux(ctx, S.aux, 1, 1));
+    RC(launch_gray_blur_hist(ctx, (const u8*)ctx->in.p, dgray, dblur, S.aux, 1, g, 1));
+    RC(launch_otsu(ctx, S.aux, 1, w * h, 1));
+    RC(launch_threshold(ctx, dblur, dbin, S.aux, 1, w, h, 1));
+    CBV_HIP(ctx, hipMemcpy2DAsync(gray, gray_stride, dgray, w, w, h, hipMemcpyDeviceToHost, ctx->stream));
+    CBV_HIP(ctx, hipMemcpy2DAsync(binary, binary_stride, dbin, w, w, h, hipMemcpyDeviceToHost, ctx->stream));
+    u32 t = 0;
+    CBV_HIP(ctx, hipMemcpyAsync(&t, S.aux + (size_t)1 * 256 + 2 + 256, 4, hipMemcpyDeviceToHost, ctx->stream));
+    CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (otsu_threshold) *otsu_threshold = (int)t;
+    return CBV_OK;
+}
+
+// enhancement chain on device buffers: src -> (A, B ping-pong) ; result pointer returned.
+// When `fold_norm` the final normalize pass is skipped and the caller applies S.norm_lut downstream.
+static int enhance_dev(cbv_ctx* ctx, const u8* src, u8* A, u8* B, Geom g, const cbv_enhance_params* P, SmallLayout S,
+                       int batch, bool fold_norm, u8** result)
+{
+    ClaheGeom cg = clahe_geom(g.w, g.h, P->clahe_clip_limit, P->tiles_x, P->tiles_y);
+    int tiles = P->tiles_x * P->tiles_y;
+    RC(launch_reset_aux(ctx, S.aux, tiles, batch));
+    RC(launch_color_lab_hist(ctx, src, A, S.aux, g, cg, batch, P->profile.enabled ? 1 : 0, 1));
+    RC(launch_clahe_lut(ctx, S.aux, S.luts, cg, batch));
+    RC(launch_clahe_apply(ctx, A, S.luts, B, g, cg, batch));
+    RC(launch_bilateral(ctx, B, A, g, batch));
+    RC(launch_sharpen(ctx, A, B, S.aux, tiles, g, P->sharpen_kernel, batch));
+    RC(launch_norm_lut(ctx, S.aux, tiles, S.norm_lut, batch));
+    if (fold_norm) {
+        *result = B;
+        return CBV_OK;
+    }
+    RC(launch_normalize(ctx, B, A, S.norm_lut, g, batch));
+    *result = A;
+    return CBV_OK;
+}
+
+static int check_params(cbv_ctx* ctx, const cbv_enhance_params* P)
+{
+    if (!P) return cbv_fail(ctx, CBV_ERR_ARG, "enhance params are null");
+    if (P->tiles_x <= 0 || P->tiles_y <= 0 || P->tiles_x > 64 || P->tiles_y > 64) return cbv_fail(ctx, CBV_ERR_ARG, "bad CLAHE tile grid");
+    RC(ctx_set_profile(ctx, &P->profile));
+    RC(ctx_set_bilateral(ctx, P->bilateral_d, P->sigma_color, P->sigma_space));
+    return CBV_OK;
+}
+
+extern "C" int cbv_process_pipeline(cbv_ctx* ctx, const uint8_t* bgr, int w, int h, int stride,
+                                    const cbv_enhance_params* params, uint8_t* out, int out_stride)
+{
+    RC(check_img(ctx, bgr, w, h, stride, 3, "cbv_process_pipeline"));
+    if (!out) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_process_pipeline: out is null");
+    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    RC(check_params(ctx, params));
+    RC(upload(ctx, &ctx->in, bgr, w * 3, h, stride));
+    Geom g = tight_geom(w, h);
+    RC(dev_ensure(ctx, &ctx->a, g.frame_stride));
+    RC(dev_ensure(ctx, &ctx->b, g.frame_stride));
+    SmallLayout S;
+    RC(small_layout(ctx, &ctx->small, params->tiles_x * params->tiles_y, 1, &S));
+    u8* res = nullptr;
+    RC(enhance_dev(ctx, (const u8*)ctx->in.p, (u8*)ctx->a.p, (u8*)ctx->b.p, g, params, S, 1, false, &res));
+    return download(ctx, res, out, w * 3, h, out_stride);
+}
+
+extern "C" int cbv_warp_perspective(cbv_ctx* ctx, const uint8_t* bgr, int w, int h, int stride, const double* M9, int dw,
+                                    int dh, int rot180, uint8_t* out, int out_stride)
+{
+    RC(check_img(ctx, bgr, w, h, stride, 3, "cbv_warp_perspective"));
+    if (!out || !M9 || dw <= 0 || dh <= 0 || dw > 8192 || dh > 8192) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_warp_perspective: bad arguments");
+    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    double Minv[9];
+    if (!host_invert3x3(M9, Minv)) memset(Minv, 0, sizeof(Minv)); // cv::invert returns a zero matrix when singular
+    RC(upload(ctx, &ctx->in, bgr, w * 3, h, stride));
+    Geom g = tight_geom(w, h);
+    RC(dev_ensure(ctx, &ctx->a, (size_t)dw * dh * 3 + 256));
+    RC(launch_warp(ctx, (const u8*)ctx->in.p, g, Minv, dw, dh, rot180, (u8*)ctx->a.p, dw * 3, (size_t)dw * dh * 3, nullptr, 1));
+    return download(ctx, ctx->a.p, out, dw * 3, dh, out_stride);
+}
+
+// ---------------------------------------------------------------------------
+// per-square detector state
+// ---------------------------------------------------------------------------
+struct cbv_squares {
+    cbv_ctx* ctx = nullptr;
+    int n = 0;
+    int blur_k = 0;
+    std::vector<SquareDesc> descs;
+    size_t plane_total = 0, mask_total = 0;
+    DevBuf d_descs, d_masks, d_gray, d_ref, d_mean, d_var, d_stats, d_select, d_coef, d_stage;
+    std::vector<u8> stage;
+    bool has_ref = false, has_model = false;
+    int coef_k = -1;
+};
+
+extern "C" int cbv_squares_create(cbv_ctx* ctx, cbv_squares** out)
+{
+    if (!ctx || !out) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_squares_create: null argument");
+    cbv_squares* s = new cbv_squares();
+    s->ctx = ctx;
+    *out = s;
+    return CBV_OK;
+}
+
+extern "C" void cbv_squares_destroy(cbv_squares* s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+    DevBuf* bufs[] = {&s->d_descs, &s->d_masks, &s->d_gray, &s->d_ref, &s->d_mean, &s->d_var, &s->d_stats, &s->d_select, &s->d_coef, &s->d_stage};
+    for (auto b : bufs) dev_free(b);
+    delete s;
+}
+
+static int squares_set_coef(cbv_squares* s, int blur_k)
+{
+    cbv_ctx* ctx = s->ctx;
+    if (blur_k < 1) blur_k = 1;
+    blur_k |= 1;
+    if (blur_k > 31) return cbv_fail(ctx, CBV_ERR_UNSUPPORTED, "blur kernel %d too large (max 31)", blur_k);
+    if (s->coef_k != blur_k) {
+        int coef[32] = {0};
+        build_gaussian_q8(blur_k, coef);
+        RC(dev_ensure(ctx, &s->d_coef, sizeof(coef)));
+        CBV_HIP(ctx, hipMemcpyAsync(s->d_coef.p, coef, sizeof(coef), hipMemcpyHostToDevice, ctx->stream));
+        CBV_HIP(ctx, hipStreamSynchronize(ctx->stream)); // coef is a stack array
+        s->coef_k = blur_k;
+    }
+    s->blur_k = blur_k;
+    return CBV_OK;
+}
+
+// (re)build geometry-dependent tables when the set of square shapes changes
+static int squares_set_geometry(cbv_squares* s, const int* ws, const int* hs, int n)
+{
+    cbv_ctx* ctx = s->ctx;
+    bool same = (n == s->n);
+    for (int i = 0; same && i < n; i++) same = s->descs[i].w == ws[i] && s->descs[i].h == hs[i];
+    if (same) return CBV_OK;
+    s->descs.assign(n, SquareDesc());
+    size_t off = 0;
+    for (int i = 0; i < n; i++) {
+        if (ws[i] <= 0 || hs[i] <= 0 || ws[i] > CBV_MAX_SQUARE_DIM || hs[i] > CBV_MAX_SQUARE_DIM)
+            return cbv_fail(ctx, CBV_ERR_UNSUPPORTED, "square %d is %dx%d; supported up to %dx%d", i, ws[i], hs[i], CBV_MAX_SQUARE_DIM, CBV_MAX_SQUARE_DIM);
+        s->descs[i].w = ws[i];
+        s->descs[i].h = hs[i];
+        s->descs[i].plane_off = (int)off;
+        s->descs[i].mask_off = (int)off;
+        off += ((size_t)ws[i] * hs[i] + 15) & ~(size_t)15;
+    }
+    s->n = n;
+    s->plane_total = off;
+    s->has_ref = s->has_model = false;
+    std::vector<u8> masks(off, 0);
+    for (int i = 0; i < n; i++) build_piece_mask(ws[i], hs[i], masks.data() + s->descs[i].mask_off);
+    RC(dev_ensure(ctx, &s->d_masks, off));
+    RC(dev_ensure(ctx, &s->d_gray, off));
+    RC(dev_ensure(ctx, &s->d_ref, off));
+    RC(dev_ensure(ctx, &s->d_mean, off * 4));
+    RC(dev_ensure(ctx, &s->d_var, off * 4));
+    RC(dev_ensure(ctx, &s->d_stats, sizeof(cbv_sq_stats) * n));
+    RC(dev_ensure(ctx, &s->d_select, CBV_MAX_SQUARES * 4));
+    RC(dev_ensure(ctx, &s->d_descs, sizeof(SquareDesc) * n));
+    CBV_HIP(ctx, hipMemcpy(s->d_masks.p, masks.data(), off, hipMemcpyHostToDevice));
+    return CBV_OK;
+}
+
+extern "C" int cbv_squares_load(cbv_squares* s, const cbv_square_view* views, int n, int blur_k)
+{
+    if (!s) return CBV_ERR_ARG;
+    cbv_ctx* ctx = s->ctx;
+    if (!views || n <= 0 || n > CBV_MAX_SQUARES) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_squares_load: bad arguments (n=%d)", n);
+    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    int ws[CBV_MAX_SQUARES], hs[CBV_MAX_SQUARES];
+    for (int i = 0; i < n; i++) {
+        if (!views[i].data) { // keep the current gray of this square (its geometry must already be known)
+            if (i >= s->n) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_squares_load: view %d is null but the square is unknown", i);
+            ws[i] = s->descs[i].w;
+            hs[i] = s->descs[i].h;
+            continue;
+        }
+        if ((views[i].cn != 1 && views[i].cn != 3) || views[i].stride < views[i].w * views[i].cn)
+            return cbv_fail(ctx, CBV_ERR_ARG, "cbv_squares_load: bad view %d", i);
+        ws[i] = views[i].w;
+        hs[i] = views[i].h;
+    }
+    RC(squares_set_geometry(s, ws, hs, n));
+    RC(squares_set_coef(s, blur_k));
+    // pack the views tightly into one staging buffer (the caller's arrays may be scattered)
+    size_t total = 0;
+    for (int i = 0; i < n; i++) {
+        if (!views[i].data) {
+            s->descs[i].cn = 0; // skipped by the kernel
+            continue;
+        }
+        s->descs[i].cn = views[i].cn;
+        s->descs[i].stride = views[i].w * views[i].cn;
+        s->descs[i].src_off = (int)total;
+        total += ((size_t)views[i].w * views[i].cn * views[i].h + 15) & ~(size_t)15;
+    }
+    if (total == 0) total = 16;
+    CBV_HIP(ctx, hipStreamSynchronize(ctx->stream)); // staging may still be in flight from the previous call
+    s->stage.resize(total);
+    for (int i = 0; i < n; i++) {
+        if (!views[i].data) continue;
+        const int rb = views[i].w * views[i].cn;
+        for (int y = 0; y < views[i].h; y++)
+            memcpy(s->stage.data() + s->descs[i].src_off + (size_t)y * rb, views[i].data + (size_t)y * views[i].stride, rb);
+    }
+    RC(dev_ensure(ctx, &s->d_stage, total));
+    CBV_HIP(ctx, hipMemcpyAsync(s->d_stage.p, s->stage.data(), total, hipMemcpyHostToDevice, ctx->stream));
+    CBV_HIP(ctx, hipMemcpyAsync(s->d_descs.p, s->descs.data(), sizeof(SquareDesc) * n, hipMemcpyHostToDevice, ctx->stream));
+    RC(launch_squares_preprocess(ctx, (const u8*)s->d_stage.p, 0, (const SquareDesc*)s->d_descs.p, n, (const int*)s->d_coef.p,
+                                 s->blur_k, (u8*)s->d_gray.p, 0, 1));
+    CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CBV_OK;
+}
+
+extern "C" int cbv_squares_load_dev(cbv_squares* s, const void* dev_img, int w, int h, int stride, int cn,
+                                    const cbv_roi* rois, int n, int blur_k)
+{
+    if (!s) return CBV_ERR_ARG;
+    cbv_ctx* ctx = s->ctx;
+    if (!dev_img || !rois || n <= 0 || n > CBV_MAX_SQUARES || (cn != 1 && cn != 3)) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_squares_load_dev: bad arguments");
+    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    int ws[CBV_MAX_SQUARES], hs[CBV_MAX_SQUARES];
+    for (int i = 0; i < n; i++) {
+        if (rois[i].x0 < 0 || rois[i].y0 < 0 || rois[i].x0 + rois[i].w > w || rois[i].y0 + rois[i].h > h)
+            return cbv_fail(ctx, CBV_ERR_ARG, "cbv_squares_load_dev: roi %d outside the image", i);
+        ws[i] = rois[i].w;
+        hs[i] = rois[i].h;
+    }
+    RC(squares_set_geometry(s, ws, hs, n));
+    RC(squares_set_coef(s, blur_k));
+    for (int i = 0; i < n; i++) {
+        s->descs[i].cn = cn;
+        s->descs[i].stride = stride;
+        s->descs[i].src_off = rois[i].y0 * stride + rois[i].x0 * cn;
+    }
+    CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CBV_HIP(ctx, hipMemcpyAsync(s->d_descs.p, s->descs.data(), sizeof(SquareDesc) * n, hipMemcpyHostToDevice, ctx->stream));
+    RC(launch_squares_preprocess(ctx, (const u8*)dev_img, 0, (const SquareDesc*)s->d_descs.p, n, (const int*)s->d_coef.p, s->blur_k,
+                                 (u8*)s->d_gray.p, 0, 1));
+    CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CBV_OK;
+}
+
+static int squares_select(cbv_squares* s, const uint8_t* select, const u8** dev)
+{
+    *dev = nullptr;
+    if (!select) return CBV_OK;
+    cbv_ctx* ctx = s->ctx;
+    CBV_HIP(ctx, hipMemcpyAsync(s->d_select.p, select, s->n, hipMemcpyHostToDevice, ctx->stream));
+    CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *dev = (const u8*)s->d_select.p;
+    return CBV_OK;
+}
+
+extern "C" int cbv_squares_calibrate(cbv_squares* s, double initial_variance, const uint8_t* select)
+{
+    if (!s) return CBV_ERR_ARG;
+    cbv_ctx* ctx = s->ctx;
+    if (s->n == 0) return cbv_fail(ctx, CBV_ERR_STATE, "cbv_squares_calibrate: no squares loaded");
+    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    const u8* sel;
+    RC(squares_select(s, select, &sel));
+    RC(launch_squares_calibrate(ctx, (const SquareDesc*)s->d_descs.p, s->n, (const u8*)s->d_gray.p, (float*)s->d_mean.p, (float*)s->d_var.p,
+                                (float)initial_variance, sel));
+    CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    s->has_model = true;
+    return CBV_OK;
+}
+
+extern "C" int cbv_squares_ema(cbv_squares* s, double alpha, const uint8_t* select)
+{
+    if (!s) return CBV_ERR_ARG;
+    cbv_ctx* ctx = s->ctx;
+    if (!s->has_model) return cbv_fail(ctx, CBV_ERR_STATE, "cbv_squares_ema: not calibrated");
+    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    const u8* sel;
+    RC(squares_select(s, select, &sel));
+    RC(launch_squares_ema(ctx, (const SquareDesc*)s->d_descs.p, s->n, (const u8*)s->d_gray.p, (float*)s->d_mean.p, (float*)s->d_var.p, alpha, sel));
+    CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CBV_OK;
+}
+
+extern "C" int cbv_squares_set_ref(cbv_squares* s, const uint8_t* select)
+{
+    if (!s) return CBV_ERR_ARG;
+    cbv_ctx* ctx = s->ctx;
+    if (s->n == 0) return cbv_fail(ctx, CBV_ERR_STATE, "cbv_squares_set_ref: no squares loaded");
+    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    const u8* sel;
+    RC(squares_select(s, select, &sel));
+    RC(launch_squares_set_ref(ctx, (const SquareDesc*)s->d_descs.p, s->n, (const u8*)s->d_gray.p, (u8*)s->d_ref.p, sel));
+    CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    s->has_ref = true;
+    return CBV_OK;
+}
+
+extern "C" int cbv_squares_stats(cbv_squares* s, int use_ref, int use_model, double z_threshold, cbv_sq_stats* out)
+{
+    if (!s) return CBV_ERR_ARG;
+    cbv_ctx* ctx = s->ctx;
+    if (!out || s->n == 0) return cbv_fail(ctx, CBV_ERR_STATE, "cbv_squares_stats: no squares loaded or null output");
+    if (use_model && !s->has_model) return cbv_fail(ctx, CBV_ERR_STATE, "cbv_squares_stats: model requested but not calibrated");
+    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    RC(launch_squares_stats(ctx, (const SquareDesc*)s->d_descs.p, s->n, (const u8*)s->d_gray.p, 0, use_ref ? (const u8*)s->d_ref.p : nullptr,
+                            use_model ? (const float*)s->d_mean.p : nullptr, use_model ? (const float*)s->d_var.p : nullptr,
+                            (const u8*)s->d_masks.p, (float)z_threshold, (cbv_sq_stats*)s->d_stats.p, 1));
+    CBV_HIP(ctx, hipMemcpyAsync(out, s->d_stats.p, sizeof(cbv_sq_stats) * s->n, hipMemcpyDeviceToHost, ctx->stream));
+    CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CBV_OK;
+}
+
+static int squares_plane(cbv_squares* s, int which, int index, void** p, size_t* bytes)
+{
+    cbv_ctx* ctx = s->ctx;
+    if (index < 0 || index >= s->n) return cbv_fail(ctx, CBV_ERR_ARG, "square index %d out of range", index);
+    const SquareDesc& d = s->descs[index];
+    size_t n = (size_t)d.w * d.h;
+    switch (which) {
+    case 0: *p = (u8*)s->d_gray.p + d.plane_off; *bytes = n; break;
+    case 1: *p = (u8*)s->d_ref.p + d.plane_off; *bytes = n; break;
+    case 2: *p = (float*)s->d_mean.p + d.plane_off; *bytes = n * 4; break;
+    case 3: *p = (float*)s->d_var.p + d.plane_off; *bytes = n * 4; break;
+    default: return cbv_fail(ctx, CBV_ERR_ARG, "bad plane selector %d", which);
+    }
+    return CBV_OK;
+}
+
+extern "C" int cbv_squares_get(cbv_squares* s, int which, int index, void* out)
+{
+    if (!s || !out) return CBV_ERR_ARG;
+    cbv_ctx* ctx = s->ctx;
+    void* p;
+    size_t bytes;
+    RC(squares_plane(s, which, index, &p, &bytes));
+    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_HIP(ctx, hipMemcpyAsync(out, p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CBV_OK;
+}
+
+extern "C" int cbv_squares_set(cbv_squares* s, int which, int index, const void* in)
+{
+    if (!s || !in) return CBV_ERR_ARG;
+    cbv_ctx* ctx = s->ctx;
+    void* p;
+    size_t bytes;
+    RC(squares_plane(s, which, index, &p, &bytes));
+    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_HIP(ctx, hipMemcpyAsync(p, in, bytes, hipMemcpyHostToDevice, ctx->stream));
+    CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (which == 1) s->has_ref = true;
+    return CBV_OK;
+}
+
+extern "C" int cbv_squares_geometry(cbv_squares* s, int index, int* w, int* h)
+{
+    if (!s || index < 0 || index >= s->n) return CBV_ERR_ARG;
+    if (w) *w = s->descs[index].w;
+    if (h) *h = s->descs[index].h;
+    return CBV_OK;
+}
+
+// ---------------------------------------------------------------------------
+// device-resident batched pipeline
+// ---------------------------------------------------------------------------
+struct cbv_pipeline {
+    cbv_ctx* ctx = nullptr;
+    int w = 0, h = 0, max_frames = 0;
+    Geom g;
+    cbv_pipeline_config cfg;
+    bool configured = false;
+    int chunk = 8;
+    double Minv[9];
+    u8* frames = nullptr;
+    u8 *A = nullptr, *B = nullptr;
+    u8* enhanced = nullptr; // [max_frames] when keep_enhanced
+    u8* warped = nullptr;   // [max_frames][S][S][3]
+    size_t warped_stride = 0;
+    DevBuf small, d_descs, d_masks, d_gray, d_stats, d_ref, d_state, d_results, d_coef, d_synth;
+    std::vector<SquareDesc> descs;
+    size_t plane_total = 0;
+    bool keep_enhanced = false;
+};
+
+extern "C" int cbv_pipeline_create(cbv_ctx* ctx, int w, int h, int max_frames, cbv_pipeline** out)
+{
+    if (!ctx || !out || w <= 0 || h <= 0 || max_frames <= 0) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_pipeline_create: bad arguments");
+    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    cbv_pipeline* p = new cbv_pipeline();
+    p->ctx = ctx;
+    p->w = w;
+    p->h = h;
+    p->max_frames = max_frames;
+    p->g = tight_geom(w, h);
+    hipError_t e = hipMalloc((void**)&p->frames, p->g.frame_stride * max_frames);
+    if (e != hipSuccess) {
+        delete p;
+        return cbv_fail(ctx, CBV_ERR_HIP, "hipMalloc of %zu bytes for the frame ring failed: %s", p->g.frame_stride * max_frames, hipGetErrorString(e));
+    }
+    *out = p;
+    return CBV_OK;
+}
+
+extern "C" void cbv_pipeline_destroy(cbv_pipeline* p)
+{
+    if (!p) return;
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipStreamSynchronize(p->ctx->stream);
+    if (p->frames) (void)hipFree(p->frames);
+    if (p->A) (void)hipFree(p->A);
+    if (p->B) (void)hipFree(p->B);
+    if (p->enhanced) (void)hipFree(p->enhanced);
+    if (p->warped) (void)hipFree(p->warped);
+    DevBuf* bufs[] = {&p->small, &p->d_descs, &p->d_masks, &p->d_gray, &p->d_stats, &p->d_ref, &p->d_state, &p->d_results, &p->d_coef, &p->d_synth};
+    for (auto b : bufs) dev_free(b);
+    delete p;
+}
+
+extern "C" void* cbv_pipeline_frames_dev(cbv_pipeline* p) { return p ? p->frames : nullptr; }
+
+extern "C" int cbv_pipeline_configure(cbv_pipeline* p, const cbv_pipeline_config* cfg)
+{
+    if (!p || !cfg) return CBV_ERR_ARG;
+    cbv_ctx* ctx = p->ctx;
+    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    if (cfg->n_rois <= 0 || cfg->n_rois > CBV_MAX_SQUARES || cfg->board_size <= 0 || cfg->board_size > 4096)
+        return cbv_fail(ctx, CBV_ERR_ARG, "cbv_pipeline_configure: bad board/roi configuration");
+    if (cfg->history_size < 1 || cfg->history_size > 31) return cbv_fail(ctx, CBV_ERR_ARG, "history_size must be in 1..31");
+    RC(check_params(ctx, &cfg->enhance));
+    CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    p->cfg = *cfg;
+    p->keep_enhanced = cfg->keep_enhanced != 0;
+    int chunk = cfg->chunk;
+    if (chunk <= 0) chunk = 8;
+    if (chunk > p->max_frames) chunk = p->max_frames;
+    p->chunk = chunk;
+    if (!host_invert3x3(cfg->M, p->Minv)) memset(p->Minv, 0, sizeof(p->Minv));
+    const int S = cfg->board_size;
+    p->warped_stride = ((size_t)S * S * 3 + 255) & ~(size_t)255;
+    // (re)allocate
+    if (p->A) (void)hipFree(p->A);
+    if (p->B) (void)hipFree(p->B);
+    if (p->warped) (void)hipFree(p->warped);
+    if (p->enhanced) (void)hipFree(p->enhanced);
+    p->A = p->B = p->warped = p->enhanced = nullptr;
+    CBV_HIP(ctx, hipMalloc((void**)&p->A, p->g.frame_stride * chunk));
+    CBV_HIP(ctx, hipMalloc((void**)&p->B, p->g.frame_stride * chunk));
+    CBV_HIP(ctx, hipMalloc((void**)&p->warped, p->warped_stride * p->max_frames));
+    if (p->keep_enhanced) CBV_HIP(ctx, hipMalloc((void**)&p->enhanced, p->g.frame_stride * p->max_frames));
+    SmallLayout SL;
+    RC(small_layout(ctx, &p->small, cfg->enhance.tiles_x * cfg->enhance.tiles_y, chunk, &SL));
+    // squares
+    const int n = cfg->n_rois;
+    p->descs.assign(n, SquareDesc());
+    size_t off = 0;
+    for (int i = 0; i < n; i++) {
+        const cbv_roi& r = cfg->rois[i];
+        if (r.w <= 0 || r.h <= 0 || r.w > CBV_MAX_SQUARE_DIM || r.h > CBV_MAX_SQUARE_DIM || r.x0 < 0 || r.y0 < 0 || r.x0 + r.w > S || r.y0 + r.h > S)
+            return cbv_fail(ctx, CBV_ERR_ARG, "roi %d is invalid for a %dx%d board", i, S, S);
+        SquareDesc& d = p->descs[i];
+        d.w = r.w;
+        d.h = r.h;
+        d.cn = 3;
+        d.stride = S * 3;
+        d.src_off = r.y0 * S * 3 + r.x0 * 3;
+        d.plane_off = (int)off;
+        d.mask_off = (int)off;
+        off += ((size_t)r.w * r.h + 15) & ~(size_t)15;
+    }
+    p->plane_total = off;
+    std::vector<u8> masks(off, 0);
+    for (int i = 0; i < n; i++) build_piece_mask(p->descs[i].w, p->descs[i].h, masks.data() + p->descs[i].mask_off);
+    RC(dev_ensure(ctx, &p->d_descs, sizeof(SquareDesc) * n));
+    RC(dev_ensure(ctx, &p->d_masks, off));
+    RC(dev_ensure(ctx, &p->d_gray, off * p->max_frames));
+    RC(dev_ensure(ctx, &p->d_stats, sizeof(cbv_sq_stats) * n * p->max_frames));
+    RC(dev_ensure(ctx, &p->d_ref, off));
+    RC(dev_ensure(ctx, &p->d_state, sizeof(ScanState) * n));
+    RC(dev_ensure(ctx, &p->d_results, sizeof(cbv_frame_result) * p->max_frames));
+    int coef[32] = {0};
+    build_gaussian_q8(5, coef);
+    RC(dev_ensure(ctx, &p->d_coef, sizeof(coef)));
+    CBV_HIP(ctx, hipMemcpy(p->d_coef.p, coef, sizeof(coef), hipMemcpyHostToDevice));
+    CBV_HIP(ctx, hipMemcpy(p->d_descs.p, p->descs.data(), sizeof(SquareDesc) * n, hipMemcpyHostToDevice));
+    CBV_HIP(ctx, hipMemcpy(p->d_masks.p, masks.data(), off, hipMemcpyHostToDevice));
+    CBV_HIP(ctx, hipMemset(p->d_state.p, 0, sizeof(ScanState) * n));
+    p->configured = true;
+    return CBV_OK;
+}
+
+extern "C" int cbv_pipeline_reset_state(cbv_pipeline* p)
+{
+    if (!p || !p->configured) return CBV_ERR_STATE;
+    cbv_ctx* ctx = p->ctx;
+    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_HIP(ctx, hipMemsetAsync(p->d_state.p, 0, sizeof(ScanState) * p->cfg.n_rois, ctx->stream));
+    return CBV_OK;
+}
+
+extern "C" int cbv_pipeline_upload(cbv_pipeline* p, int slot, const uint8_t* bgr, int stride)
+{
+    if (!p || !bgr || slot < 0 || slot >= p->max_frames || stride < p->w * 3) return CBV_ERR_ARG;
+    cbv_ctx* ctx = p->ctx;
+    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_HIP(ctx, hipMemcpy2DAsync(p->frames + p->g.frame_stride * slot, p->w * 3, bgr, stride, p->w * 3, p->h, hipMemcpyHostToDevice, ctx->stream));
+    CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CBV_OK;
+}
+
+extern "C" int cbv_pipeline_synth(cbv_pipeline* p, int slot0, int count, const uint64_t* seeds, const double* Hinv9,
+                                  const uint8_t* boards, const cbv_scene* scene)
+{
+    if (!p || !seeds || !Hinv9 || !boards || !scene || slot0 < 0 || count <= 0 || slot0 + count > p->max_frames) return CBV_ERR_ARG;
+    cbv_ctx* ctx = p->ctx;
+    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    size_t o_seeds = 0, o_h = (size_t)count * 8, o_b = o_h + 72, o_s = (o_b + (size_t)count * 64 + 15) & ~(size_t)15;
+    size_t total = o_s + sizeof(cbv_scene);
+    CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RC(dev_ensure(ctx, &p->d_synth, total));
+    std::vector<u8> host(total, 0);
+    memcpy(host.data() + o_seeds, seeds, (size_t)count * 8);
+    memcpy(host.data() + o_h, Hinv9, 72);
+    memcpy(host.data() + o_b, boards, (size_t)count * 64);
+    memcpy(host.data() + o_s, scene, sizeof(cbv_scene));
+    CBV_HIP(ctx, hipMemcpy(p->d_synth.p, host.data(), total, hipMemcpyHostToDevice));
+    u8* base = (u8*)p->d_synth.p;
+    RC(launch_synth(ctx, p->frames + p->g.frame_stride * slot0, p->g, (const u64*)(base + o_seeds), (const double*)(base + o_h),
+                    base + o_b, (const cbv_scene*)(base + o_s), count));
+    CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CBV_OK;
+}
+
+extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
+{
+    if (!p || !p->configured) return CBV_ERR_STATE;
+    cbv_ctx* ctx = p->ctx;
+    if (slot0 < 0 || count <= 0 || slot0 + count > p->max_frames) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_pipeline_run: bad slot range");
+    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    const cbv_pipeline_config& cfg = p->cfg;
+    const int S = cfg.board_size, n = cfg.n_rois;
+    SmallLayout SL;
+    RC(small_layout(ctx, &p->small, cfg.enhance.tiles_x * cfg.enhance.tiles_y, p->chunk, &SL));
+    Geom wg; // geometry of the warped board images
+    wg.w = S;
+    wg.h = S;
+    wg.stride = S * 3;
+    wg.frame_stride = p->warped_stride;
+    for (int s0 = slot0; s0 < slot0 + count; s0 += p->chunk) {
+        const int b = std::min(p->chunk, slot0 + count - s0);
+        const u8* src = p->frames + p->g.frame_stride * s0;
+        u8* res = nullptr;
+        RC(enhance_dev(ctx, src, p->A, p->B, p->g, &cfg.enhance, SL, b, !p->keep_enhanced, &res));
+        u8* wdst = p->warped + p->warped_stride * s0;
+        if (p->keep_enhanced) {
+            CBV_HIP(ctx, hipMemcpyAsync(p->enhanced + p->g.frame_stride * s0, res, p->g.frame_stride * b, hipMemcpyDeviceToDevice, ctx->stream));
+            RC(launch_warp(ctx, res, p->g, p->Minv, S, S, cfg.rot180, wdst, S * 3, p->warped_stride, nullptr, b));
+        } else {
+            RC(launch_warp(ctx, res, p->g, p->Minv, S, S, cfg.rot180, wdst, S * 3, p->warped_stride, SL.norm_lut, b));
+        }
+        RC(launch_squares_preprocess(ctx, wdst, p->warped_stride, (const SquareDesc*)p->d_descs.p, n, (const int*)p->d_coef.p, 5,
+                                     (u8*)p->d_gray.p + p->plane_total * s0, p->plane_total, b));
+        RC(launch_squares_stats(ctx, (const SquareDesc*)p->d_descs.p, n, (const u8*)p->d_gray.p + p->plane_total * s0, p->plane_total, nullptr,
+                                nullptr, nullptr, (const u8*)p->d_masks.p, 0.f, (cbv_sq_stats*)p->d_stats.p + (size_t)n * s0, b));
+    }
+    CBV_HIP(ctx, hipMemsetAsync((cbv_frame_result*)p->d_results.p + slot0, 0, sizeof(cbv_frame_result) * count, ctx->stream));
+    ScanParams sp;
+    sp.n = n;
+    sp.history_size = cfg.history_size;
+    sp.min_presence = cfg.min_presence;
+    sp.change_threshold = cfg.change_threshold;
+    RC(launch_scan(ctx, (const SquareDesc*)p->d_descs.p, sp, (const u8*)p->d_gray.p + p->plane_total * slot0, p->plane_total,
+                   (const cbv_sq_stats*)p->d_stats.p + (size_t)n * slot0, (u8*)p->d_ref.p, (ScanState*)p->d_state.p,
+                   (cbv_frame_result*)p->d_results.p + slot0, count));
+    (void)wg;
+    return CBV_OK;
+}
+
+extern "C" int cbv_pipeline_results(cbv_pipeline* p, int slot0, int count, cbv_frame_result* out)
+{
+    if (!p || !out || slot0 < 0 || count <= 0 || slot0 + count > p->max_frames) return CBV_ERR_ARG;
+    cbv_ctx* ctx = p->ctx;
+    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_HIP(ctx, hipMemcpyAsync(out, (cbv_frame_result*)p->d_results.p + slot0, sizeof(cbv_frame_result) * count, hipMemcpyDeviceToHost, ctx->stream));
+    CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CBV_OK;
+}
+
+extern "C" int cbv_pipeline_download(cbv_pipeline* p, int which, int slot, uint8_t* out)
+{
+    if (!p || !out || slot < 0 || slot >= p->max_frames) return CBV_ERR_ARG;
+    cbv_ctx* ctx = p->ctx;
+    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    const u8* src;
+    size_t bytes;
+    if (which == 0) {
+        src = p->frames + p->g.frame_stride * slot;
+        bytes = (size_t)p->w * p->h * 3;
+    } else if (which == 1) {
+        if (!p->enhanced) return cbv_fail(ctx, CBV_ERR_STATE, "enhanced frames are not kept (configure with keep_enhanced = 1)");
+        src = p->enhanced + p->g.frame_stride * slot;
+        bytes = (size_t)p->w * p->h * 3;
+    } else if (which == 2) {
+        if (!p->warped) return cbv_fail(ctx, CBV_ERR_STATE, "pipeline not configured");
+        src = p->warped + p->warped_stride * slot;
+        bytes = (size_t)p->cfg.board_size * p->cfg.board_size * 3;
+    } else
+        return cbv_fail(ctx, CBV_ERR_ARG, "bad buffer selector %d", which);
+    CBV_HIP(ctx, hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CBV_OK;
+}
+
+extern "C" int cbv_pipeline_square_stats(cbv_pipeline* p, int slot, cbv_sq_stats* out)
+{
+    if (!p || !out || !p->configured || slot < 0 || slot >= p->max_frames) return CBV_ERR_ARG;
+    cbv_ctx* ctx = p->ctx;
+    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_HIP(ctx, hipMemcpyAsync(out, (cbv_sq_stats*)p->d_stats.p + (size_t)p->cfg.n_rois * slot, sizeof(cbv_sq_stats) * p->cfg.n_rois,
+                                hipMemcpyDeviceToHost, ctx->stream));
+    CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CBV_OK;
+}

@@ -1,0 +1,201 @@
+// Internal declarations shared by the HIP translation units of libcbv_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/cbv.h"
+
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+// ---------------------------------------------------------------------------
+// constant tables (device copies live in cbv_ctx::tabs)
+// ---------------------------------------------------------------------------
+enum {
+    LAB_SHIFT = 12, GAMMA_SHIFT = 3, LAB_SHIFT2 = LAB_SHIFT + GAMMA_SHIFT,
+    LAB_CBRT_TAB_SIZE_B = 256 * 3 / 2 * (1 << GAMMA_SHIFT),
+    INV_GAMMA_SHIFT = 12, INV_GAMMA_TAB_SIZE = 1 << INV_GAMMA_SHIFT,
+    LAB_BASE_SHIFT = 14, LAB_BASE = 1 << LAB_BASE_SHIFT
+};
+
+struct StaticTabs {
+    int sdiv[256];                       // RGB2HSV_b saturation divisors
+    int hdiv[256];                       // RGB2HSV_b hue divisors (hrange 180)
+    u16 gamma[256];                      // sRGBGammaTab_b
+    u16 cbrt[LAB_CBRT_TAB_SIZE_B];       // LabCbrtTab_b
+    u16 inv_gamma[INV_GAMMA_TAB_SIZE];   // sRGBInvGammaTab_b
+    u16 lab_yf[512];                     // LabToYF_b (y, ify) pairs
+    int fwd[9];                          // RGB2Lab_b coefficients (BGR order)
+    int inv[9];                          // Lab2RGBinteger coefficients
+};
+
+// apply_color_profile reduced to byte->byte tables (frame_enhancer.py:71-97)
+struct ProfileTabs {
+    u8 csa[256];      // convertScaleAbs(alpha=contrast, beta=brightness)
+    u8 hmap[256];     // clip((h + hue_shift) % 180, 0, 179) -> uint8
+    u8 vmap[256];     // clip(v * val_scale, 0, 255) -> uint8
+    u8 smap[2][256];  // [radical mask][s]: clip(s * {1, 0.5, 2} * sat_scale, 0, 255) -> uint8
+    u8 hmask[256];    // radical-mode window membership of h
+    int enabled;
+};
+
+struct BilateralTabs {
+    float color_w[768];
+    float space_w[128];
+    signed char dy[128], dx[128];
+    int maxk, radius;
+};
+
+void build_static_tabs(StaticTabs* t);
+void build_profile_tabs(const cbv_color_profile* p, ProfileTabs* t);
+int build_bilateral_tabs(int d, double sigma_color, double sigma_space, BilateralTabs* t);
+void build_gaussian_q8(int k, int* coef);
+void build_piece_mask(int w, int h, u8* mask);
+int host_invert3x3(const double* S, double* D);
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct ProfSlot {
+    hipEvent_t a, b;
+    int kid;
+};
+
+struct cbv_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    char devname[256] = {0};
+    int num_cus = 256;
+
+    StaticTabs* tabs = nullptr;          // device
+    ProfileTabs* ptabs = nullptr;        // device, current profile
+    cbv_color_profile ptabs_key;
+    bool ptabs_valid = false;
+    BilateralTabs* btabs = nullptr;      // device
+    BilateralTabs btabs_host;
+    int b_d = -1;
+    double b_sc = 0, b_ss = 0;
+
+    // scratch for the host-buffer entry points
+    DevBuf in, a, b, c, small;
+
+    // profiling
+    int prof_kid = -2;
+    std::vector<ProfSlot> prof_pending;
+    std::vector<hipEvent_t> prof_pool;
+    double prof_ms[CBV_K_COUNT] = {0};
+    long long prof_n[CBV_K_COUNT] = {0};
+};
+
+extern thread_local std::string g_cbv_err;
+int cbv_fail(cbv_ctx* ctx, int code, const char* fmt, ...);
+
+#define CBV_HIP(ctx, call)                                                                          \
+    do {                                                                                            \
+        hipError_t e__ = (call);                                                                    \
+        if (e__ != hipSuccess)                                                                      \
+            return cbv_fail(ctx, CBV_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), \
+                            __FILE__, __LINE__);                                                    \
+    } while (0)
+
+int dev_ensure(cbv_ctx* ctx, DevBuf* b, size_t bytes);
+void dev_free(DevBuf* b);
+int ctx_set_profile(cbv_ctx* ctx, const cbv_color_profile* p);
+int ctx_set_bilateral(cbv_ctx* ctx, int d, double sc, double ss);
+
+// RAII-less helpers to bracket a launch with profiling events
+void prof_begin(cbv_ctx* ctx, int kid);
+void prof_end(cbv_ctx* ctx, int kid);
+
+// ---------------------------------------------------------------------------
+// frame geometry for batched launches: `batch` frames, each frame_stride bytes
+// apart, rows `stride` bytes apart.
+// ---------------------------------------------------------------------------
+struct Geom {
+    int w, h;
+    int stride;          // bytes per row
+    size_t frame_stride; // bytes between consecutive frames of a batch
+};
+
+struct ClaheGeom {
+    int tiles_x, tiles_y, tw, th; // tile size of the (possibly extended) image
+    int clip;                     // integer clip limit (0 = none)
+    float lut_scale;
+    int divisible;                // image dims divisible by the tile grid
+};
+ClaheGeom clahe_geom(int w, int h, double clip_limit, int tiles_x, int tiles_y);
+
+// per-frame small device state of the enhancement chain
+struct FrameAux {
+    u32 hist[1];  // layout helper only
+};
+// layout of the per-frame aux block (u32 units)
+//   [0 .. T*256)         CLAHE histograms
+//   then 2               min, max of the sharpen output
+//   then 256             otsu histogram
+//   then 1               otsu threshold
+__host__ __device__ static inline size_t aux_words(int tiles) { return (size_t)tiles * 256 + 2 + 256 + 2; }
+
+// ---------------------------------------------------------------------------
+// kernel launchers (device pointers; asynchronous on ctx->stream)
+// ---------------------------------------------------------------------------
+int launch_reset_aux(cbv_ctx* ctx, u32* aux, int tiles, int batch);
+int launch_color_lab_hist(cbv_ctx* ctx, const u8* src, u8* lab, u32* aux, Geom g, ClaheGeom cg, int batch,
+                          int do_profile, int do_lab);
+int launch_clahe_lut(cbv_ctx* ctx, const u32* aux, u8* luts, ClaheGeom cg, int batch);
+int launch_clahe_apply(cbv_ctx* ctx, const u8* lab, const u8* luts, u8* dst, Geom g, ClaheGeom cg, int batch);
+int launch_bilateral(cbv_ctx* ctx, const u8* src, u8* dst, Geom g, int batch);
+int launch_sharpen(cbv_ctx* ctx, const u8* src, u8* dst, u32* aux, int tiles, Geom g, const float* k9, int batch);
+int launch_norm_lut(cbv_ctx* ctx, const u32* aux, int tiles, u8* norm_lut, int batch);
+int launch_normalize(cbv_ctx* ctx, const u8* src, u8* dst, const u8* norm_lut, Geom g, int batch);
+int launch_warp(cbv_ctx* ctx, const u8* src, Geom g, const double* Minv9, int dw, int dh, int rot180, u8* dst,
+                int dst_stride, size_t dst_frame_stride, const u8* norm_lut, int batch);
+int launch_gray_blur_hist(cbv_ctx* ctx, const u8* src, u8* gray, u8* blur, u32* aux, int tiles, Geom g, int batch);
+int launch_otsu(cbv_ctx* ctx, u32* aux, int tiles, int total, int batch);
+int launch_threshold(cbv_ctx* ctx, const u8* blur, u8* binary, const u32* aux, int tiles, int w, int h, int batch);
+int launch_synth(cbv_ctx* ctx, u8* dst, Geom g, const u64* seeds_dev, const double* hinv_dev, const u8* boards_dev,
+                 const cbv_scene* scene_dev, int batch);
+
+// squares
+struct SquareDesc {
+    int w, h;
+    int src_off;   // byte offset of the ROI origin inside the source image / staging
+    int stride;    // source row stride in bytes
+    int cn;
+    int plane_off; // element offset of this square's planes (gray/ref/mean/var)
+    int mask_off;  // byte offset into the mask table
+    int pad;
+};
+int launch_squares_preprocess(cbv_ctx* ctx, const u8* src, size_t src_frame_stride, const SquareDesc* descs, int n,
+                              const int* coef_dev, int blur_k, u8* gray, size_t gray_frame_stride, int batch);
+int launch_squares_stats(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, size_t gray_frame_stride,
+                         const u8* ref, const float* mean, const float* var, const u8* masks, float z_thresh,
+                         cbv_sq_stats* out, int batch);
+int launch_squares_calibrate(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, float* mean, float* var,
+                             float init_var, const u8* select);
+int launch_squares_ema(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, float* mean, float* var,
+                       double alpha, const u8* select);
+int launch_squares_set_ref(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, u8* ref, const u8* select);
+
+struct ScanParams {
+    int n;               // squares
+    int history_size;
+    double min_presence;
+    double change_threshold;
+};
+struct ScanState {       // per square, device resident
+    u32 has_ref, has_cache, cached_raw, hist_len, hist_bits;
+};
+int launch_scan(cbv_ctx* ctx, const SquareDesc* descs, ScanParams sp, const u8* gray, size_t gray_frame_stride,
+                const cbv_sq_stats* stats, u8* ref, ScanState* state, cbv_frame_result* results, int count);

@@ -1,0 +1,665 @@
+// Enhancement kernels except the bilateral filter:
+//   k_color_lab_hist  apply_color_profile + BGR2LAB + per-tile L histograms
+//   k_clahe_lut       clip / redistribute / cumulative LUT per tile
+//   k_clahe_apply     bilinear LUT interpolation on L + LAB2BGR
+//   k_sharpen         3x3 filter2D (REFLECT_101) + global min/max
+//   k_norm_lut        NORM_MINMAX scale/shift -> 256-entry byte map
+//   k_normalize       byte map
+// All memory-bound: pixels move as 12-byte groups (4 BGR pixels = 3 dwords
+// per lane, 768 contiguous bytes per wave); tables sit in LDS.
+#include "cbv_device.h"
+
+// ---------------------------------------------------------------------------
+__global__ void k_reset_aux(u32* aux, int tiles, int batch)
+{
+    size_t per = aux_words(tiles);
+    size_t total = per * batch;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t k = i % per;
+        aux[i] = (k == (size_t)tiles * 256) ? 255u : 0u; // [min] starts at 255, everything else 0
+    }
+}
+
+int launch_reset_aux(cbv_ctx* ctx, u32* aux, int tiles, int batch)
+{
+    size_t total = aux_words(tiles) * batch;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    prof_begin(ctx, CBV_K_RESET);
+    hipLaunchKernelGGL(k_reset_aux, dim3(blocks), dim3(256), 0, ctx->stream, aux, tiles, batch);
+    prof_end(ctx, CBV_K_RESET);
+    CBV_HIP(ctx, hipGetLastError());
+    return CBV_OK;
+}
+
+// ---------------------------------------------------------------------------
+// colour profile + BGR2LAB + tile histograms
+// ---------------------------------------------------------------------------
+struct ColorLds {
+    int sdiv[256];
+    int hdiv[256];
+    u16 gamma[256];
+    u16 cbrt[LAB_CBRT_TAB_SIZE_B];
+    ProfileTabs pt;
+    int fwd[9];
+    u32 hist[256 * 8]; // 8 bank-interleaved copies: hist[bin * 8 + (lane & 7)]
+};
+
+// RGB2HSV_b -> table maps of the numpy section -> HSV2RGB_b (float)
+__device__ __forceinline__ void d_profile_px(const ColorLds& L, int& b, int& g, int& r)
+{
+    b = L.pt.csa[b];
+    g = L.pt.csa[g];
+    r = L.pt.csa[r];
+    int v = max(b, max(g, r)), vmin = min(b, min(g, r));
+    int diff = v - vmin;
+    int vr = v == r ? -1 : 0, vg = v == g ? -1 : 0;
+    int s = (diff * L.sdiv[v] + (1 << 11)) >> 12;
+    int h = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
+    h = (h * L.hdiv[diff] + (1 << 11)) >> 12;
+    h += h < 0 ? 180 : 0;
+    h = d_sat8(h);
+    // numpy float32 section as byte maps
+    int m = L.pt.hmask[h];
+    int hh = L.pt.hmap[h];
+    int ss = L.pt.smap[m][s & 255];
+    int vv = L.pt.vmap[v];
+    // HSV2RGB_b
+    float fh = (float)hh;
+    float fs = (float)ss * (1.0f / 255.0f);
+    float fv = (float)vv * (1.0f / 255.0f);
+    float fb, fg, fr;
+    if (fs == 0.f) {
+        fb = fg = fr = fv;
+    } else {
+        fh = fh * (6.0f / 180.0f);
+        fh = fh >= 6.f ? fh - 6.f : fh; // == fmodf(fh, 6) for fh in [0, 12)
+        int sector = d_floor_f(fh);
+        fh = fh - (float)sector;
+        if ((unsigned)sector >= 6u) {
+            sector = 0;
+            fh = 0.f;
+        }
+        float t0 = fv;
+        float t1 = fv * (1.f - fs);
+        float t2 = fv * (1.f - fs * fh);
+        float t3 = fv * (1.f - fs * (1.f - fh));
+        // sector table {1,3,0},{1,0,2},{3,0,1},{0,2,1},{0,1,3},{2,1,0}
+        fb = sector == 0 ? t1 : sector == 1 ? t1 : sector == 2 ? t3 : sector == 3 ? t0 : sector == 4 ? t0 : t2;
+        fg = sector == 0 ? t3 : sector == 1 ? t0 : sector == 2 ? t0 : sector == 3 ? t2 : sector == 4 ? t1 : t1;
+        fr = sector == 0 ? t0 : sector == 1 ? t2 : sector == 2 ? t1 : sector == 3 ? t1 : sector == 4 ? t3 : t0;
+    }
+    b = d_sat8_f(fb * 255.0f);
+    g = d_sat8_f(fg * 255.0f);
+    r = d_sat8_f(fr * 255.0f);
+}
+
+// RGB2Lab_b (integer)
+__device__ __forceinline__ void d_bgr2lab_px(const ColorLds& L, int b, int g, int r, int& oL, int& oa, int& ob)
+{
+    const int Lscale = (116 * 255 + 50) / 100;
+    const int Lshift = -((16 * 255 * (1 << LAB_SHIFT2) + 50) / 100);
+    int R = L.gamma[b], G = L.gamma[g], B = L.gamma[r]; // positional naming as in OpenCV
+    int fX = L.cbrt[D_DESCALE(R * L.fwd[0] + G * L.fwd[1] + B * L.fwd[2], LAB_SHIFT)];
+    int fY = L.cbrt[D_DESCALE(R * L.fwd[3] + G * L.fwd[4] + B * L.fwd[5], LAB_SHIFT)];
+    int fZ = L.cbrt[D_DESCALE(R * L.fwd[6] + G * L.fwd[7] + B * L.fwd[8], LAB_SHIFT)];
+    oL = d_sat8(D_DESCALE(Lscale * fY + Lshift, LAB_SHIFT2));
+    oa = d_sat8(D_DESCALE(500 * (fX - fY) + 128 * (1 << LAB_SHIFT2), LAB_SHIFT2));
+    ob = d_sat8(D_DESCALE(200 * (fY - fZ) + 128 * (1 << LAB_SHIFT2), LAB_SHIFT2));
+}
+
+// grid: x = row slices of a tile, y = tile, z = frame.  One wave per row.
+__global__ __launch_bounds__(256) void k_color_lab_hist(const u8* __restrict__ src, u8* __restrict__ dst,
+                                                         u32* __restrict__ aux, Geom g, ClaheGeom cg,
+                                                         const StaticTabs* __restrict__ st,
+                                                         const ProfileTabs* __restrict__ pt, int rows_per_wg,
+                                                         int do_profile, int do_lab, int tiles_total)
+{
+    __shared__ ColorLds L;
+    lds_copy(L.sdiv, st->sdiv, sizeof(L.sdiv));
+    lds_copy(L.hdiv, st->hdiv, sizeof(L.hdiv));
+    lds_copy(L.gamma, st->gamma, sizeof(L.gamma));
+    lds_copy(L.cbrt, st->cbrt, sizeof(L.cbrt));
+    lds_copy(&L.pt, pt, sizeof(ProfileTabs));
+    if (threadIdx.x < 9) L.fwd[threadIdx.x] = st->fwd[threadIdx.x];
+    for (int i = threadIdx.x; i < 256 * 8; i += blockDim.x) L.hist[i] = 0;
+    __syncthreads();
+
+    const int tile = blockIdx.y;
+    const int tx = tile % cg.tiles_x, ty = tile / cg.tiles_x;
+    const size_t fo = (size_t)blockIdx.z * g.frame_stride;
+    const u8* sf = src + fo;
+    u8* df = dst + fo;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * rows_per_wg;
+    const int r1 = min(r0 + rows_per_wg, cg.th);
+    const int ex0 = tx * cg.tw;
+    const bool aligned = ((cg.tw & 3) == 0) && ((g.stride & 3) == 0);
+    const int groups = (cg.tw + 3) >> 2;
+
+    for (int rr = r0 + wave; rr < r1; rr += 4) {
+        const int ey = ty * cg.th + rr;
+        const int sy = d_reflect101(ey, g.h);
+        const bool row_in = ey < g.h;
+        for (int gi = lane; gi < groups; gi += 64) {
+            const int ex = ex0 + gi * 4;
+            const int npx = min(4, cg.tw - gi * 4);
+            Px4 px, out;
+            out.d[0] = out.d[1] = out.d[2] = 0;
+            const bool fast = aligned && npx == 4 && ex + 3 < g.w;
+            if (fast) {
+                const u32* p = (const u32*)(sf + (size_t)sy * g.stride + (size_t)ex * 3);
+                px.d[0] = p[0];
+                px.d[1] = p[1];
+                px.d[2] = p[2];
+            } else {
+                px.d[0] = px.d[1] = px.d[2] = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (k < npx) {
+                        int sx = d_reflect101(ex + k, g.w);
+                        const u8* p = sf + (size_t)sy * g.stride + (size_t)sx * 3;
+                        px_set(px, 3 * k, p[0]);
+                        px_set(px, 3 * k + 1, p[1]);
+                        px_set(px, 3 * k + 2, p[2]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (k < npx) {
+                    int b = px_get(px, 3 * k), gg = px_get(px, 3 * k + 1), r = px_get(px, 3 * k + 2);
+                    if (do_profile) d_profile_px(L, b, gg, r);
+                    if (do_lab) {
+                        int oL, oa, ob;
+                        d_bgr2lab_px(L, b, gg, r, oL, oa, ob);
+                        atomicAdd(&L.hist[oL * 8 + (lane & 7)], 1u);
+                        b = oL;
+                        gg = oa;
+                        r = ob;
+                    }
+                    px_set(out, 3 * k, b);
+                    px_set(out, 3 * k + 1, gg);
+                    px_set(out, 3 * k + 2, r);
+                }
+            }
+            if (row_in) {
+                if (fast) {
+                    u32* q = (u32*)(df + (size_t)ey * g.stride + (size_t)ex * 3);
+                    q[0] = out.d[0];
+                    q[1] = out.d[1];
+                    q[2] = out.d[2];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        if (k < npx && ex + k < g.w) {
+                            u8* q = df + (size_t)ey * g.stride + (size_t)(ex + k) * 3;
+                            q[0] = (u8)px_get(out, 3 * k);
+                            q[1] = (u8)px_get(out, 3 * k + 1);
+                            q[2] = (u8)px_get(out, 3 * k + 2);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (do_lab) {
+        __syncthreads();
+        u32* hist = aux + (size_t)blockIdx.z * aux_words(tiles_total) + (size_t)tile * 256;
+        for (int bin = threadIdx.x; bin < 256; bin += blockDim.x) {
+            u32 s = 0;
+#pragma unroll
+            for (int c = 0; c < 8; c++) s += L.hist[bin * 8 + c];
+            if (s) atomicAdd(&hist[bin], s);
+        }
+    }
+}
+
+int launch_color_lab_hist(cbv_ctx* ctx, const u8* src, u8* lab, u32* aux, Geom g, ClaheGeom cg, int batch,
+                          int do_profile, int do_lab)
+{
+    const int rows_per_wg = 8;
+    dim3 grid((cg.th + rows_per_wg - 1) / rows_per_wg, cg.tiles_x * cg.tiles_y, batch);
+    prof_begin(ctx, CBV_K_COLOR_LAB_HIST);
+    hipLaunchKernelGGL(k_color_lab_hist, grid, dim3(256), 0, ctx->stream, src, lab, aux, g, cg, ctx->tabs, ctx->ptabs,
+                       rows_per_wg, do_profile, do_lab, cg.tiles_x * cg.tiles_y);
+    prof_end(ctx, CBV_K_COLOR_LAB_HIST);
+    CBV_HIP(ctx, hipGetLastError());
+    return CBV_OK;
+}
+
+// ---------------------------------------------------------------------------
+// CLAHE LUT: one workgroup (256 threads = 256 bins) per tile
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_clahe_lut(const u32* __restrict__ aux, u8* __restrict__ luts, ClaheGeom cg,
+                                                    int tiles_total)
+{
+    __shared__ int red[4];
+    __shared__ int scan[256];
+    const int tile = blockIdx.x, t = threadIdx.x;
+    const u32* hist = aux + (size_t)blockIdx.y * aux_words(tiles_total) + (size_t)tile * 256;
+    int hv = (int)hist[t];
+    if (cg.clip > 0) {
+        int excess = hv > cg.clip ? hv - cg.clip : 0;
+        hv = min(hv, cg.clip);
+        int ws = (int)wave_sum_u32((u32)excess);
+        if ((t & 63) == 0) red[t >> 6] = ws;
+        __syncthreads();
+        int clipped = red[0] + red[1] + red[2] + red[3];
+        int batch = clipped / 256;
+        int residual = clipped - batch * 256;
+        hv += batch;
+        if (residual != 0) {
+            int step = max(256 / residual, 1);
+            if (t % step == 0 && t / step < residual) hv++;
+        }
+    }
+    // inclusive scan over the 256 bins
+    scan[t] = hv;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        int v = t >= o ? scan[t - o] : 0;
+        __syncthreads();
+        scan[t] += v;
+        __syncthreads();
+    }
+    float f = (float)scan[t] * cg.lut_scale;
+    luts[((size_t)blockIdx.y * tiles_total + tile) * 256 + t] = d_sat8_f(f);
+}
+
+int launch_clahe_lut(cbv_ctx* ctx, const u32* aux, u8* luts, ClaheGeom cg, int batch)
+{
+    int tiles = cg.tiles_x * cg.tiles_y;
+    prof_begin(ctx, CBV_K_CLAHE_LUT);
+    hipLaunchKernelGGL(k_clahe_lut, dim3(tiles, batch), dim3(256), 0, ctx->stream, aux, luts, cg, tiles);
+    prof_end(ctx, CBV_K_CLAHE_LUT);
+    CBV_HIP(ctx, hipGetLastError());
+    return CBV_OK;
+}
+
+// ---------------------------------------------------------------------------
+// CLAHE interpolation + LAB2BGR.  Rows are cut into bands that share the same
+// pair of LUT rows (ty1, ty2), so a workgroup stages just two LUT rows.
+// grid: x = chunk of `rows_per_wg` rows inside a band, y = band, z = frame.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int d_ab_to_xz(int i)
+{
+    if (i <= 3390) return i * 108 / 841 - LAB_BASE * 16 / 116 * 108 / 841;
+    return i * i / LAB_BASE * i / LAB_BASE;
+}
+
+__global__ __launch_bounds__(256) void k_clahe_apply(const u8* __restrict__ lab, const u8* __restrict__ luts,
+                                                      u8* __restrict__ dst, Geom g, ClaheGeom cg,
+                                                      const StaticTabs* __restrict__ st, int rows_per_wg,
+                                                      int tiles_total)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    u16* inv_gamma = (u16*)smem;                               // 8192 B
+    u16* lab_yf = (u16*)(smem + INV_GAMMA_TAB_SIZE * 2);       // 1024 B
+    int* invc = (int*)(smem + INV_GAMMA_TAB_SIZE * 2 + 1024);  // 64 B (9 used)
+    u8* lut1 = smem + INV_GAMMA_TAB_SIZE * 2 + 1024 + 64;      // tiles_x * 256
+    u8* lut2 = lut1 + cg.tiles_x * 256;
+
+    // band b holds the rows whose unclamped ty1 is b - 1
+    const int band = blockIdx.y;
+    const float inv_th = 1.0f / cg.th, inv_tw = 1.0f / cg.tw;
+    // first row of the band: smallest y with floor(y*inv_th - 0.5) >= band-1; search near the estimate
+    int yb0, yb1;
+    {
+        int est = (int)((band - 0.5f) * cg.th);
+        int y = min(max(est - 2, 0), g.h);
+        while (y < g.h && d_floor_f((float)y * inv_th - 0.5f) < band - 1) y++;
+        yb0 = y;
+        int est1 = (int)((band + 0.5f) * cg.th);
+        y = min(max(est1 - 2, yb0), g.h);
+        while (y < g.h && d_floor_f((float)y * inv_th - 0.5f) < band) y++;
+        yb1 = y;
+    }
+    const int y0 = yb0 + blockIdx.x * rows_per_wg;
+    if (y0 >= yb1) return;
+    const int y1 = min(y0 + rows_per_wg, yb1);
+    const int ty1c = min(max(band - 1, 0), cg.tiles_y - 1), ty2c = min(band, cg.tiles_y - 1);
+
+    lds_copy(inv_gamma, st->inv_gamma, INV_GAMMA_TAB_SIZE * 2);
+    lds_copy(lab_yf, st->lab_yf, 1024);
+    if (threadIdx.x < 9) invc[threadIdx.x] = st->inv[threadIdx.x];
+    const u8* lf = luts + (size_t)blockIdx.z * tiles_total * 256;
+    lds_copy(lut1, lf + (size_t)ty1c * cg.tiles_x * 256, cg.tiles_x * 256);
+    lds_copy(lut2, lf + (size_t)ty2c * cg.tiles_x * 256, cg.tiles_x * 256);
+    __syncthreads();
+
+    const size_t fo = (size_t)blockIdx.z * g.frame_stride;
+    const u8* sf = lab + fo;
+    u8* df = dst + fo;
+    const bool aligned = (g.stride & 3) == 0;
+    const int groups = (g.w + 3) >> 2;
+    const int nrows = y1 - y0;
+    const int shift = LAB_SHIFT + (LAB_BASE_SHIFT - INV_GAMMA_SHIFT);
+
+    for (int it = threadIdx.x; it < groups * nrows; it += blockDim.x) {
+        const int row = it / groups, gi = it - row * groups;
+        const int y = y0 + row, x0 = gi * 4;
+        const int npx = min(4, g.w - x0);
+        const float tyf = (float)y * inv_th - 0.5f;
+        const float ya = tyf - (float)d_floor_f(tyf), ya1 = 1.0f - ya;
+        Px4 px, out;
+        out.d[0] = out.d[1] = out.d[2] = 0;
+        const bool fast = aligned && npx == 4;
+        const u8* p = sf + (size_t)y * g.stride + (size_t)x0 * 3;
+        if (fast) {
+            const u32* pw = (const u32*)p;
+            px.d[0] = pw[0];
+            px.d[1] = pw[1];
+            px.d[2] = pw[2];
+        } else {
+            px.d[0] = px.d[1] = px.d[2] = 0;
+#pragma unroll
+            for (int k = 0; k < 12; k++)
+                if (k < npx * 3) px_set(px, k, p[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (k < npx) {
+                const int x = x0 + k;
+                const float txf = (float)x * inv_tw - 0.5f;
+                int tx1 = d_floor_f(txf);
+                const float xa = txf - (float)tx1, xa1 = 1.0f - xa;
+                int tx2 = min(tx1 + 1, cg.tiles_x - 1);
+                tx1 = max(tx1, 0);
+                const int v = px_get(px, 3 * k);
+                float ra = (float)lut1[tx1 * 256 + v] * xa1 + (float)lut1[tx2 * 256 + v] * xa;
+                float rb = (float)lut2[tx1 * 256 + v] * xa1 + (float)lut2[tx2 * 256 + v] * xa;
+                float res = ra * ya1 + rb * ya;
+                const int LL = d_sat8_f(res);
+                // Lab2RGBinteger
+                const int aa = px_get(px, 3 * k + 1), bb = px_get(px, 3 * k + 2);
+                const int yv = lab_yf[LL * 2], ify = lab_yf[LL * 2 + 1];
+                const int adiv = ((5 * aa * 53687 + (1 << 7)) >> 13) - 128 * LAB_BASE / 500;
+                const int bdiv = ((bb * 41943 + (1 << 4)) >> 9) - 128 * LAB_BASE / 200 + 1;
+                const int xv = d_ab_to_xz(ify + adiv), zv = d_ab_to_xz(ify - bdiv);
+                int ro = D_DESCALE(invc[0] * xv + invc[1] * yv + invc[2] * zv, shift);
+                int go = D_DESCALE(invc[3] * xv + invc[4] * yv + invc[5] * zv, shift);
+                int bo = D_DESCALE(invc[6] * xv + invc[7] * yv + invc[8] * zv, shift);
+                ro = min(max(ro, 0), INV_GAMMA_TAB_SIZE - 1);
+                go = min(max(go, 0), INV_GAMMA_TAB_SIZE - 1);
+                bo = min(max(bo, 0), INV_GAMMA_TAB_SIZE - 1);
+                px_set(out, 3 * k, d_sat8(inv_gamma[bo]));
+                px_set(out, 3 * k + 1, d_sat8(inv_gamma[go]));
+                px_set(out, 3 * k + 2, d_sat8(inv_gamma[ro]));
+            }
+        }
+        u8* q = df + (size_t)y * g.stride + (size_t)x0 * 3;
+        if (fast) {
+            u32* qw = (u32*)q;
+            qw[0] = out.d[0];
+            qw[1] = out.d[1];
+            qw[2] = out.d[2];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 12; k++)
+                if (k < npx * 3) q[k] = (u8)px_get(out, k);
+        }
+    }
+}
+
+int launch_clahe_apply(cbv_ctx* ctx, const u8* lab, const u8* luts, u8* dst, Geom g, ClaheGeom cg, int batch)
+{
+    const int rows_per_wg = 4;
+    int tiles = cg.tiles_x * cg.tiles_y;
+    size_t lds = INV_GAMMA_TAB_SIZE * 2 + 1024 + 64 + 2 * (size_t)cg.tiles_x * 256;
+    if (lds > 64 * 1024) return cbv_fail(ctx, CBV_ERR_UNSUPPORTED, "clahe: tile grid too wide (%d)", cg.tiles_x);
+    // a band is at most th rows (+1 for rounding)
+    dim3 grid((cg.th + 1 + rows_per_wg - 1) / rows_per_wg, cg.tiles_y + 1, batch);
+    prof_begin(ctx, CBV_K_CLAHE_APPLY);
+    hipLaunchKernelGGL(k_clahe_apply, grid, dim3(256), lds, ctx->stream, lab, luts, dst, g, cg, ctx->tabs, rows_per_wg,
+                       tiles);
+    prof_end(ctx, CBV_K_CLAHE_APPLY);
+    CBV_HIP(ctx, hipGetLastError());
+    return CBV_OK;
+}
+
+// ---------------------------------------------------------------------------
+// 3x3 filter2D + global min/max.  Tile: 256 px x 16 rows; rows staged in LDS
+// as raw bytes with a 1-pixel (3-byte) halo; each lane produces 4 px x 4 rows.
+// ---------------------------------------------------------------------------
+#define SH_TW 256
+#define SH_TH 16
+#define SH_PITCH (SH_TW * 3 + 8) // bytes per LDS row: 4 left (1 pad + 3 halo), 768, 3 halo + 1 pad
+
+__global__ __launch_bounds__(256) void k_sharpen(const u8* __restrict__ src, u8* __restrict__ dst,
+                                                  u32* __restrict__ aux, int tiles_total, Geom g, float k0, float k1,
+                                                  float k2, float k3, float k4, float k5, float k6, float k7,
+                                                  float k8, int tiles_xn, int tiles_n)
+{
+    __shared__ __attribute__((aligned(16))) u8 tile[(SH_TH + 2) * SH_PITCH];
+    __shared__ int red[8];
+    const int tid = xcd_remap(blockIdx.x, tiles_n);
+    const int tyi = tid / tiles_xn, txi = tid - tyi * tiles_xn;
+    const int x0 = txi * SH_TW, y0 = tyi * SH_TH;
+    const size_t fo = (size_t)blockIdx.z * g.frame_stride;
+    const u8* sf = src + fo;
+    u8* df = dst + fo;
+    const int wb = g.w * 3;
+    // stage rows y0-1 .. y0+SH_TH, bytes [x0*3-4, x0*3+768+4)
+    const int b0 = x0 * 3 - 4;
+    const bool aligned = (g.stride & 3) == 0;
+    for (int i = threadIdx.x; i < (SH_TH + 2) * (SH_PITCH / 4); i += blockDim.x) {
+        const int r = i / (SH_PITCH / 4), c = i - r * (SH_PITCH / 4);
+        const int sy = d_reflect101(y0 - 1 + r, g.h);
+        const int bs = b0 + c * 4;
+        u32 v;
+        if (aligned && bs >= 0 && bs + 3 < wb) {
+            v = *(const u32*)(sf + (size_t)sy * g.stride + bs);
+        } else {
+            v = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int bx = bs + k;
+                // byte bx belongs to pixel floor(bx/3) (may be -1 or w); reflect the pixel, keep the channel
+                int pxl = bx >= 0 ? bx / 3 : -((2 - bx) / 3);
+                int ch = bx - pxl * 3;
+                int spx = d_reflect101(pxl, g.w);
+                u32 byte = (pxl >= -1 && pxl <= g.w) ? sf[(size_t)sy * g.stride + spx * 3 + ch] : 0;
+                v |= byte << (8 * k);
+            }
+        }
+        *(u32*)&tile[r * SH_PITCH + c * 4] = v;
+    }
+    __syncthreads();
+
+    const int lane_x = threadIdx.x & 63, rq = threadIdx.x >> 6; // 64 column groups x 4 row quads
+    const int x = x0 + lane_x * 4;
+    int mn = 255, mx = 0;
+    if (x < g.w) {
+        const int npx = min(4, g.w - x);
+        // window of a lane: tile bytes [12*lane_x, 12*lane_x + 24); bytes 1..18 of it are
+        // the 3-byte halo, the 12 output bytes and the right halo.
+        float f[3][18];
+        auto load_row = [&](int slot, int trow) {
+            const u32* wr = (const u32*)&tile[trow * SH_PITCH + lane_x * 12];
+            u32 wv[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) wv[k] = wr[k];
+#pragma unroll
+            for (int j = 0; j < 18; j++) f[slot][j] = (float)((wv[(j + 1) >> 2] >> (((j + 1) & 3) * 8)) & 255);
+        };
+        load_row(0, rq * 4 + 0);
+        load_row(1, rq * 4 + 1);
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            const int ly = rq * 4 + rr;
+            const int y = y0 + ly;
+            load_row((rr + 2) % 3, ly + 2);
+            const float* r0 = f[rr % 3];
+            const float* r1 = f[(rr + 1) % 3];
+            const float* r2 = f[(rr + 2) % 3];
+            Px4 out;
+            out.d[0] = out.d[1] = out.d[2] = 0;
+#pragma unroll
+            for (int j = 0; j < 12; j++) {
+                float s = k0 * r0[j];
+                s = s + k1 * r0[j + 3];
+                s = s + k2 * r0[j + 6];
+                s = s + k3 * r1[j];
+                s = s + k4 * r1[j + 3];
+                s = s + k5 * r1[j + 6];
+                s = s + k6 * r2[j];
+                s = s + k7 * r2[j + 3];
+                s = s + k8 * r2[j + 6];
+                int o = d_sat8_f(s);
+                px_set(out, j, o);
+                if (j < npx * 3 && y < g.h) {
+                    mn = min(mn, o);
+                    mx = max(mx, o);
+                }
+            }
+            if (y < g.h) {
+                u8* q = df + (size_t)y * g.stride + (size_t)x * 3;
+                if (aligned && npx == 4) {
+                    u32* qw = (u32*)q;
+                    qw[0] = out.d[0];
+                    qw[1] = out.d[1];
+                    qw[2] = out.d[2];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 12; j++)
+                        if (j < npx * 3) q[j] = (u8)px_get(out, j);
+                }
+            }
+        }
+    }
+    mn = wave_min_i32(mn);
+    mx = wave_max_i32(mx);
+    if ((threadIdx.x & 63) == 0) {
+        red[rq] = mn;
+        red[4 + rq] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32* mm = aux + (size_t)blockIdx.z * aux_words(tiles_total) + (size_t)tiles_total * 256;
+        atomicMin(&mm[0], (u32)min(min(red[0], red[1]), min(red[2], red[3])));
+        atomicMax(&mm[1], (u32)max(max(red[4], red[5]), max(red[6], red[7])));
+    }
+}
+
+int launch_sharpen(cbv_ctx* ctx, const u8* src, u8* dst, u32* aux, int tiles, Geom g, const float* k, int batch)
+{
+    int txn = (g.w + SH_TW - 1) / SH_TW, tyn = (g.h + SH_TH - 1) / SH_TH;
+    prof_begin(ctx, CBV_K_SHARPEN);
+    hipLaunchKernelGGL(k_sharpen, dim3(txn * tyn, 1, batch), dim3(256), 0, ctx->stream, src, dst, aux, tiles, g, k[0],
+                       k[1], k[2], k[3], k[4], k[5], k[6], k[7], k[8], txn, txn * tyn);
+    prof_end(ctx, CBV_K_SHARPEN);
+    CBV_HIP(ctx, hipGetLastError());
+    return CBV_OK;
+}
+
+// ---------------------------------------------------------------------------
+// NORM_MINMAX as a byte map
+// ---------------------------------------------------------------------------
+__global__ void k_norm_lut(const u32* __restrict__ aux, int tiles_total, u8* __restrict__ norm_lut)
+{
+    const u32* mm = aux + (size_t)blockIdx.x * aux_words(tiles_total) + (size_t)tiles_total * 256;
+    double smin = (double)(int)mm[0], smax = (double)(int)mm[1];
+    double scale = 255.0 * (smax - smin > 2.2204460492503131e-16 ? 1. / (smax - smin) : 0.);
+    double shift = 0.0 - smin * scale;
+    float a = (float)scale, b = (float)shift;
+    float t = (float)(int)threadIdx.x * a;
+    t = t + b;
+    norm_lut[(size_t)blockIdx.x * 256 + threadIdx.x] = d_sat8_f(t);
+}
+
+int launch_norm_lut(cbv_ctx* ctx, const u32* aux, int tiles, u8* norm_lut, int batch)
+{
+    prof_begin(ctx, CBV_K_NORM_LUT);
+    hipLaunchKernelGGL(k_norm_lut, dim3(batch), dim3(256), 0, ctx->stream, aux, tiles, norm_lut);
+    prof_end(ctx, CBV_K_NORM_LUT);
+    CBV_HIP(ctx, hipGetLastError());
+    return CBV_OK;
+}
+
+// rows are mapped 16 bytes per lane
+__global__ __launch_bounds__(256) void k_normalize(const u8* __restrict__ src, u8* __restrict__ dst,
+                                                    const u8* __restrict__ norm_lut, Geom g, int blocks_per_frame)
+{
+    __shared__ u8 lut[256];
+    lut[threadIdx.x] = norm_lut[(size_t)blockIdx.z * 256 + threadIdx.x];
+    __syncthreads();
+    const size_t fo = (size_t)blockIdx.z * g.frame_stride;
+    const int wb = g.w * 3;
+    const bool flat = (g.stride == wb) && ((g.frame_stride & 15) == 0);
+    if (flat) {
+        const size_t total = (size_t)wb * g.h;
+        const size_t nvec = total / 16;
+        const uint4* s = (const uint4*)(src + fo);
+        uint4* d = (uint4*)(dst + fo);
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)blocks_per_frame * blockDim.x) {
+            uint4 v = s[i];
+            u32 w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                u32 x = w4[k];
+                w4[k] = (u32)lut[x & 255] | ((u32)lut[(x >> 8) & 255] << 8) | ((u32)lut[(x >> 16) & 255] << 16) |
+                        ((u32)lut[x >> 24] << 24);
+            }
+            d[i] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+        }
+        if (blockIdx.x == 0)
+            for (size_t i = nvec * 16 + threadIdx.x; i < total; i += blockDim.x) dst[fo + i] = lut[src[fo + i]];
+    } else {
+        for (int y = blockIdx.x; y < g.h; y += blocks_per_frame)
+            for (int x = threadIdx.x; x < wb; x += blockDim.x)
+                dst[fo + (size_t)y * g.stride + x] = lut[src[fo + (size_t)y * g.stride + x]];
+    }
+}
+
+int launch_normalize(cbv_ctx* ctx, const u8* src, u8* dst, const u8* norm_lut, Geom g, int batch)
+{
+    size_t nvec = (size_t)g.w * 3 * g.h / 16;
+    int blocks = (int)((nvec + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    prof_begin(ctx, CBV_K_NORMALIZE);
+    hipLaunchKernelGGL(k_normalize, dim3(blocks, 1, batch), dim3(256), 0, ctx->stream, src, dst, norm_lut, g, blocks);
+    prof_end(ctx, CBV_K_NORMALIZE);
+    CBV_HIP(ctx, hipGetLastError());
+    return CBV_OK;
+}
+
+// ---------------------------------------------------------------------------
+// stand-alone global min/max (normalize_intensity called on its own)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_minmax(const u8* __restrict__ src, u32* __restrict__ aux, int tiles_total, Geom g)
+{
+    __shared__ int red[8];
+    const size_t fo = (size_t)blockIdx.z * g.frame_stride;
+    const int wb = g.w * 3;
+    int mn = 255, mx = 0;
+    for (int y = blockIdx.x; y < g.h; y += gridDim.x) {
+        const u8* row = src + fo + (size_t)y * g.stride;
+        for (int x = threadIdx.x; x < wb; x += blockDim.x) {
+            const int v = row[x];
+            mn = min(mn, v);
+            mx = max(mx, v);
+        }
+    }
+    mn = wave_min_i32(mn);
+    mx = wave_max_i32(mx);
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6] = mn;
+        red[4 + (threadIdx.x >> 6)] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32* mm = aux + (size_t)blockIdx.z * aux_words(tiles_total) + (size_t)tiles_total * 256;
+        atomicMin(&mm[0], (u32)min(min(red[0], red[1]), min(red[2], red[3])));
+        atomicMax(&mm[1], (u32)max(max(red[4], red[5]), max(red[6], red[7])));
+    }
+}
+
+int launch_minmax(cbv_ctx* ctx, const u8* src, u32* aux, int tiles, Geom g, int batch)
+{
+    int blocks = g.h < 512 ? g.h : 512;
+    hipLaunchKernelGGL(k_minmax, dim3(blocks, 1, batch), dim3(256), 0, ctx->stream, src, aux, tiles, g);
+    CBV_HIP(ctx, hipGetLastError());
+    return CBV_OK;
+}

@@ -1,0 +1,341 @@
+// Per-square work of ChangeDetector (change_detector.py) and PieceDetector
+// (piece_detector.py).  One workgroup per square (<= 128 x 128 px):
+//   k_squares_preprocess  BGR2GRAY + GaussianBlur((k,k),0) on the ROI alone
+//                         (REFLECT_101 at the square's own edges)
+//   k_squares_stats       every sum the host/device decision chains need
+//   k_squares_calibrate / _ema / _set_ref   background-model state updates
+//   k_scan                detect_all_pieces' temporal logic over a batch of
+//                         frames: 64 independent per-square chains
+#include "cbv_device.h"
+
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_squares_preprocess(const u8* __restrict__ src, size_t src_frame_stride,
+                                                             const SquareDesc* __restrict__ descs,
+                                                             const int* __restrict__ coef, int blur_k,
+                                                             u8* __restrict__ gray, size_t gray_frame_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    const SquareDesc d = descs[blockIdx.x];
+    if (d.cn == 0) return; // square not supplied in this call: its current gray is kept
+    const int n = d.w * d.h;
+    u8* g = smem;                                   // n bytes
+    u16* hb = (u16*)(smem + ((n + 15) & ~15));      // n u16
+    __shared__ int cf[32];
+    if (threadIdx.x < blur_k && threadIdx.x < 32) cf[threadIdx.x] = coef[threadIdx.x];
+    const u8* s = src + (size_t)blockIdx.z * src_frame_stride + d.src_off;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int y = i / d.w, x = i - y * d.w;
+        const u8* p = s + (size_t)y * d.stride + (size_t)x * d.cn;
+        g[i] = d.cn == 3 ? (u8)d_gray(p[0], p[1], p[2]) : p[0];
+    }
+    __syncthreads();
+    u8* out = gray + (size_t)blockIdx.z * gray_frame_stride + d.plane_off;
+    if (blur_k <= 1) {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] = g[i];
+        return;
+    }
+    const int r = blur_k >> 1;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int y = i / d.w, x = i - y * d.w;
+        u32 acc = 0;
+        for (int j = 0; j < blur_k; j++) acc += (u32)cf[j] * g[y * d.w + d_reflect101(x + j - r, d.w)];
+        hb[i] = (u16)min(acc, 65535u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int y = i / d.w, x = i - y * d.w;
+        u32 acc = 0;
+        for (int j = 0; j < blur_k; j++) acc += (u32)cf[j] * hb[d_reflect101(y + j - r, d.h) * d.w + x];
+        const u32 v = (acc + (1u << 15)) >> 16;
+        out[i] = (u8)min(v, 255u);
+    }
+}
+
+int launch_squares_preprocess(cbv_ctx* ctx, const u8* src, size_t src_frame_stride, const SquareDesc* descs, int n,
+                              const int* coef_dev, int blur_k, u8* gray, size_t gray_frame_stride, int batch)
+{
+    size_t lds = (size_t)((CBV_MAX_SQUARE_DIM * CBV_MAX_SQUARE_DIM + 15) & ~15) + 2 * CBV_MAX_SQUARE_DIM * CBV_MAX_SQUARE_DIM;
+    prof_begin(ctx, CBV_K_SQUARES);
+    hipLaunchKernelGGL(k_squares_preprocess, dim3(n, 1, batch), dim3(256), lds, ctx->stream, src, src_frame_stride,
+                       descs, coef_dev, blur_k, gray, gray_frame_stride);
+    prof_end(ctx, CBV_K_SQUARES);
+    CBV_HIP(ctx, hipGetLastError());
+    return CBV_OK;
+}
+
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_squares_stats(const SquareDesc* __restrict__ descs,
+                                                        const u8* __restrict__ gray, size_t gray_frame_stride,
+                                                        const u8* __restrict__ ref, const float* __restrict__ mean,
+                                                        const float* __restrict__ var, const u8* __restrict__ masks,
+                                                        float z_thresh, cbv_sq_stats* __restrict__ out, int nsq)
+{
+    __shared__ u32 acc[20];
+    __shared__ float zm[4];
+    __shared__ int nanf_[1];
+    const SquareDesc d = descs[blockIdx.x];
+    const int n = d.w * d.h;
+    if (threadIdx.x < 20) acc[threadIdx.x] = 0;
+    if (threadIdx.x == 0) nanf_[0] = 0;
+    __syncthreads();
+    const u8* g = gray + (size_t)blockIdx.z * gray_frame_stride + d.plane_off;
+    const u8* m = masks + d.mask_off;
+    u32 v[17];
+#pragma unroll
+    for (int k = 0; k < 17; k++) v[k] = 0;
+    float zmax = 0.f;
+    int nan_seen = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int gv = g[i];
+        const u32 mk = m[i];
+        v[0] += gv;
+        v[1] += gv * gv;
+        if (ref) v[2] += (u32)abs(gv - (int)ref[d.plane_off + i]);
+        v[3] += (mk & 1) ? gv : 0;
+        v[4] += (mk & 1);
+        v[5] += (mk & 2) ? gv : 0;
+        v[6] += (mk >> 1) & 1;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            v[7 + k] += (mk & (4u << k)) ? gv : 0;
+            v[11 + k] += (mk >> (2 + k)) & 1;
+        }
+        if (mean) {
+            // change_detector.py:131-137 in float32: sqrt and division are IEEE-rounded
+            const float sd = __fsqrt_rn(var[d.plane_off + i]);
+            const float df = fabsf((float)gv - mean[d.plane_off + i]);
+            const float z = __fdiv_rn(df, sd);
+            if (z > z_thresh) v[15]++;
+            if (z != z) nan_seen = 1;
+            else zmax = fmaxf(zmax, z);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        u32 s = wave_sum_u32(v[k]);
+        if ((threadIdx.x & 63) == 0 && s) atomicAdd(&acc[k], s);
+    }
+    zmax = wave_max_f32(zmax);
+    if ((threadIdx.x & 63) == 0) zm[threadIdx.x >> 6] = zmax;
+    if (nan_seen) nanf_[0] = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        cbv_sq_stats st;
+        st.n = (u32)n;
+        st.sum = acc[0];
+        st.sumsq = acc[1];
+        st.sad_ref = acc[2];
+        st.center_sum = acc[3];
+        st.center_cnt = acc[4];
+        st.border_sum = acc[5];
+        st.border_cnt = acc[6];
+        for (int k = 0; k < 4; k++) {
+            st.ring_sum[k] = acc[7 + k];
+            st.ring_cnt[k] = acc[11 + k];
+        }
+        st.z_count = acc[15];
+        float z = fmaxf(fmaxf(zm[0], zm[1]), fmaxf(zm[2], zm[3]));
+        st.z_max = nanf_[0] ? __builtin_nanf("") : z;
+        out[(size_t)blockIdx.z * nsq + blockIdx.x] = st;
+    }
+}
+
+int launch_squares_stats(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, size_t gray_frame_stride,
+                         const u8* ref, const float* mean, const float* var, const u8* masks, float z_thresh,
+                         cbv_sq_stats* out, int batch)
+{
+    prof_begin(ctx, CBV_K_SQUARES);
+    hipLaunchKernelGGL(k_squares_stats, dim3(n, 1, batch), dim3(256), 0, ctx->stream, descs, gray, gray_frame_stride,
+                       ref, mean, var, masks, z_thresh, out, n);
+    prof_end(ctx, CBV_K_SQUARES);
+    CBV_HIP(ctx, hipGetLastError());
+    return CBV_OK;
+}
+
+// ---------------------------------------------------------------------------
+__global__ void k_squares_calibrate(const SquareDesc* __restrict__ descs, const u8* __restrict__ gray,
+                                    float* __restrict__ mean, float* __restrict__ var, float init_var,
+                                    const u8* __restrict__ select)
+{
+    if (select && !select[blockIdx.x]) return;
+    const SquareDesc d = descs[blockIdx.x];
+    for (int i = threadIdx.x; i < d.w * d.h; i += blockDim.x) {
+        mean[d.plane_off + i] = (float)gray[d.plane_off + i];
+        var[d.plane_off + i] = init_var;
+    }
+}
+
+// update_all_references (change_detector.py:77-92), float32, one rounding per op
+__global__ void k_squares_ema(const SquareDesc* __restrict__ descs, const u8* __restrict__ gray,
+                              float* __restrict__ mean, float* __restrict__ var, float one_minus, float alpha,
+                              const u8* __restrict__ select)
+{
+    if (select && !select[blockIdx.x]) return;
+    const SquareDesc d = descs[blockIdx.x];
+    for (int i = threadIdx.x; i < d.w * d.h; i += blockDim.x) {
+        const float gv = (float)gray[d.plane_off + i];
+        const float m1 = one_minus * mean[d.plane_off + i];
+        const float m2 = alpha * gv;
+        const float nm = m1 + m2;
+        const float df = gv - nm;
+        const float d2 = df * df;
+        const float v1 = one_minus * var[d.plane_off + i];
+        const float v2 = alpha * d2;
+        float nv = v1 + v2;
+        if (!(nv >= 10.0f)) nv = (nv != nv) ? nv : 10.0f; // np.maximum propagates NaN
+        mean[d.plane_off + i] = nm;
+        var[d.plane_off + i] = nv;
+    }
+}
+
+__global__ void k_squares_set_ref(const SquareDesc* __restrict__ descs, const u8* __restrict__ gray,
+                                  u8* __restrict__ ref, const u8* __restrict__ select)
+{
+    if (select && !select[blockIdx.x]) return;
+    const SquareDesc d = descs[blockIdx.x];
+    for (int i = threadIdx.x; i < d.w * d.h; i += blockDim.x) ref[d.plane_off + i] = gray[d.plane_off + i];
+}
+
+int launch_squares_calibrate(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, float* mean, float* var,
+                             float init_var, const u8* select)
+{
+    hipLaunchKernelGGL(k_squares_calibrate, dim3(n), dim3(256), 0, ctx->stream, descs, gray, mean, var, init_var, select);
+    CBV_HIP(ctx, hipGetLastError());
+    return CBV_OK;
+}
+
+int launch_squares_ema(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, float* mean, float* var,
+                       double alpha, const u8* select)
+{
+    // (1 - self.alpha) and self.alpha are python doubles turned float32 by numpy (weak scalars)
+    float one_minus = (float)(1.0 - alpha), a = (float)alpha;
+    hipLaunchKernelGGL(k_squares_ema, dim3(n), dim3(256), 0, ctx->stream, descs, gray, mean, var, one_minus, a, select);
+    CBV_HIP(ctx, hipGetLastError());
+    return CBV_OK;
+}
+
+int launch_squares_set_ref(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, u8* ref, const u8* select)
+{
+    hipLaunchKernelGGL(k_squares_set_ref, dim3(n), dim3(256), 0, ctx->stream, descs, gray, ref, select);
+    CBV_HIP(ctx, hipGetLastError());
+    return CBV_OK;
+}
+
+// ---------------------------------------------------------------------------
+// PieceDetector.detect_piece decision chain without HoughCircles
+// (piece_detector.py:303-345), evaluated in double like numpy does.
+// ---------------------------------------------------------------------------
+__device__ bool d_detect_piece(const cbv_sq_stats& st)
+{
+    // np.std(gray) < 15  <=>  n*sumsq - sum^2 < 225 n^2   (exact integer form)
+    const long long n = st.n, s = st.sum;
+    const long long lhs = n * (long long)st.sumsq - s * s;
+    if (lhs < 225ll * n * n) return false;
+    const double cm = (double)st.center_sum / (double)st.center_cnt;
+    const double bm = (double)st.border_sum / (double)st.border_cnt;
+    const double diff = fabs(cm - bm);
+    if (diff > 40.0) return true;
+    double rm[4];
+    int nr = 0;
+    for (int k = 0; k < 4; k++)
+        if (st.ring_cnt[k] > 0) rm[nr++] = (double)st.ring_sum[k] / (double)st.ring_cnt[k];
+    if (nr < 2) return false;
+    double sum = 0;
+    for (int k = 0; k < nr; k++) sum = sum + rm[k];
+    const double mean = sum / nr;
+    double sq = 0;
+    for (int k = 0; k < nr; k++) {
+        const double x = rm[k] - mean;
+        sq = sq + x * x;
+    }
+    const double variance = sq / nr;
+    const double score = fmin(1.0, variance / 500.0);
+    return score > 0.6;
+}
+
+// detect_all_pieces(use_smoothing=True, use_delta=True, squares_to_check=None)
+// (piece_detector.py:348-440) over `count` consecutive frames; one workgroup
+// per square, state carried in ScanState and `ref`.
+__global__ __launch_bounds__(256) void k_scan(const SquareDesc* __restrict__ descs, ScanParams sp,
+                                               const u8* __restrict__ gray, size_t gray_frame_stride,
+                                               const cbv_sq_stats* __restrict__ stats, u8* __restrict__ ref,
+                                               ScanState* __restrict__ state, cbv_frame_result* __restrict__ results,
+                                               int count)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    __shared__ u32 red[4];
+    __shared__ int flag[1];
+    const int sq = blockIdx.x;
+    const SquareDesc d = descs[sq];
+    const int n = d.w * d.h;
+    u8* lref = smem;
+    ScanState st = state[sq];
+    if (st.has_ref)
+        for (int i = threadIdx.x; i < n; i += blockDim.x) lref[i] = ref[d.plane_off + i];
+    __syncthreads();
+    for (int t = 0; t < count; t++) {
+        const u8* g = gray + (size_t)t * gray_frame_stride + d.plane_off;
+        u32 sad = 0;
+        if (st.has_ref)
+            for (int i = threadIdx.x; i < n; i += blockDim.x) sad += (u32)abs((int)g[i] - (int)lref[i]);
+        sad = wave_sum_u32(sad);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sad;
+        __syncthreads();
+        // every thread evaluates the (cheap, uniform) decision chain
+        const u32 tot = red[0] + red[1] + red[2] + red[3];
+        bool changed = true;
+        if (st.has_ref) {
+            const double mean_diff = (double)tot / (double)n;
+            changed = mean_diff > sp.change_threshold;
+        }
+        const bool should_process = !st.has_cache || changed;
+        bool raw;
+        if (should_process) {
+            raw = d_detect_piece(stats[(size_t)t * sp.n + sq]);
+            st.cached_raw = raw;
+            st.has_cache = 1;
+        } else {
+            raw = st.cached_raw != 0;
+        }
+        // _update_history / _get_stable_detection
+        st.hist_bits = (st.hist_bits << 1) | (raw ? 1u : 0u);
+        if ((int)st.hist_len < sp.history_size) st.hist_len++;
+        st.hist_bits &= (1u << st.hist_len) - 1u;
+        bool stable;
+        if (st.hist_len < 3) stable = raw;
+        else {
+            const double presence = (double)__popc(st.hist_bits) / (double)st.hist_len;
+            stable = presence >= sp.min_presence;
+        }
+        const bool update = should_process && (raw == stable);
+        if (update) {
+            for (int i = threadIdx.x; i < n; i += blockDim.x) lref[i] = g[i];
+            st.has_ref = 1;
+        }
+        if (threadIdx.x == 0) {
+            cbv_frame_result* r = &results[t];
+            const u64 bit = 1ull << sq;
+            if (raw) atomicOr((unsigned long long*)&r->raw_occupied, bit);
+            if (stable) atomicOr((unsigned long long*)&r->stable_occupied, bit);
+            if (changed) atomicOr((unsigned long long*)&r->visual_changes, bit);
+            if (should_process) atomicOr((unsigned long long*)&r->processed, bit);
+        }
+        __syncthreads();
+    }
+    if (st.has_ref)
+        for (int i = threadIdx.x; i < n; i += blockDim.x) ref[d.plane_off + i] = lref[i];
+    if (threadIdx.x == 0) state[sq] = st;
+    (void)flag;
+}
+
+int launch_scan(cbv_ctx* ctx, const SquareDesc* descs, ScanParams sp, const u8* gray, size_t gray_frame_stride,
+                const cbv_sq_stats* stats, u8* ref, ScanState* state, cbv_frame_result* results, int count)
+{
+    size_t lds = CBV_MAX_SQUARE_DIM * CBV_MAX_SQUARE_DIM;
+    prof_begin(ctx, CBV_K_SCAN);
+    hipLaunchKernelGGL(k_scan, dim3(sp.n), dim3(256), lds, ctx->stream, descs, sp, gray, gray_frame_stride, stats, ref,
+                       state, results, count);
+    prof_end(ctx, CBV_K_SCAN);
+    CBV_HIP(ctx, hipGetLastError());
+    return CBV_OK;
+}

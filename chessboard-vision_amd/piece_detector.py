@@ -1,0 +1,181 @@
+"""PieceDetector on MI355X — drop-in for piece_detector.py.
+
+The GPU produces, for every square, the preprocessed gray image (BGR2GRAY +
+5x5 Gaussian on the square alone) and the integer sums the decision chain
+needs; the chain itself (thresholds, temporal smoothing, reference refresh)
+runs here with the reference's own arithmetic (float64 means, np.var).
+
+Not reproduced: cv2.HoughCircles (piece_detector.py:210-270).  `has_piece` is
+the OR of Hough, centre-vs-border and radial symmetry; this class evaluates the
+latter two, so `method` is never 'hough'/'tower_top' (SURVEY.md H2).
+"""
+import json
+import os
+
+import numpy as np
+
+from . import _native as N
+from ._squares import REF, PlaneDict, SquareSet
+
+SETTINGS_FILE = "piece_detector_settings.json"
+
+
+class PieceDetectorHIP:
+    def __init__(self):
+        self.min_radius_ratio = 0.20
+        self.max_radius_ratio = 0.55
+        self.edge_threshold = 50
+        self.circle_threshold = 0.6
+
+        self.history_size = 5
+        self.min_presence = 0.6
+        self.detection_history = {}
+
+        self.load_settings()
+
+        self._state = SquareSet()        # the board's squares: gray + reference planes
+        self._scratch = SquareSet(self._state.ctx)  # single squares passed to detect_piece
+        self.reference_squares = PlaneDict(self._state, REF)
+        self.cached_results = {}
+        self.change_threshold = 25
+
+    def load_settings(self):
+        """Radii from piece_detector_settings.json in the cwd (piece_detector.py:52-68)."""
+        if os.path.exists(SETTINGS_FILE):
+            try:
+                with open(SETTINGS_FILE, "r") as f:
+                    params = json.load(f)
+                if "min_radius" in params:
+                    self.min_radius_ratio = params["min_radius"] / 100.0
+                if "max_radius" in params:
+                    self.max_radius_ratio = params["max_radius"] / 100.0
+                print(f"[PieceDetector] Settings loaded from {SETTINGS_FILE}")
+            except Exception as e:
+                print(f"[PieceDetector] Error loading settings: {e}")
+
+    # -- decision chain on device statistics ----------------------------------
+    def _decide(self, st, shape):
+        """piece_detector.py:289-345 for one square given its cbv_sq_stats."""
+        h, w = shape
+        result = {"has_piece": False, "confidence": 0.0, "center": None, "radius": None, "method": None,
+                  "center_border_diff": 0, "is_ellipse": False, "axes": None}
+        n, s, ss = int(st.n), int(st.sum), int(st.sumsq)
+        # np.std(gray) < 15  <=>  n*sumsq - sum^2 < 225 n^2
+        if n * ss - s * s < 225 * n * n:
+            return result
+        center_mean = np.float64(st.center_sum) / st.center_cnt if st.center_cnt else np.float64("nan")
+        border_mean = np.float64(st.border_sum) / st.border_cnt if st.border_cnt else np.float64("nan")
+        diff = abs(center_mean - border_mean)
+        result["center_border_diff"] = diff
+        if diff > 40:
+            result.update(has_piece=True, center=(w // 2, h // 2), radius=min(h, w) // 3, method="center_diff",
+                          confidence=min(1.0, diff / 80))
+            return result
+        ring_means = [np.float64(st.ring_sum[k]) / st.ring_cnt[k] for k in range(4) if st.ring_cnt[k] > 0]
+        symmetry = 0.0 if len(ring_means) < 2 else min(1.0, np.var(ring_means) / 500)
+        if symmetry > self.circle_threshold:
+            result.update(has_piece=True, center=(w // 2, h // 2), radius=min(h, w) // 3, method="symmetry", confidence=symmetry)
+        return result
+
+    def _preprocess_square(self, square_img):
+        self._scratch.load({0: square_img}, 5)
+        return self._scratch.get(0, 0)
+
+    def _detect_many(self, imgs):
+        """detect_piece for a list of independent square images, one device round trip."""
+        if not imgs:
+            return []
+        out = []
+        for i0 in range(0, len(imgs), N.MAX_SQUARES):
+            part = {i: im for i, im in enumerate(imgs[i0:i0 + N.MAX_SQUARES])}
+            self._scratch.load(part, 5)
+            st = self._scratch.stats()
+            out += [self._decide(st[i], self._scratch.shapes[i]) for i in range(len(part))]
+        return out
+
+    def detect_piece(self, square_img, pos=None):
+        return self._detect_many([square_img])[0]
+
+    # -- reference handling ----------------------------------------------------
+    def calibrate_reference(self, squares_dict):
+        """piece_detector.py:70-80"""
+        self.reference_squares.clear()
+        self.cached_results.clear()
+        self._state.load(squares_dict, 5)
+        self._state.set_ref(None)
+        self.reference_squares._mark(self._state.keys)
+        st = self._state.stats()
+        for i, pos in enumerate(self._state.keys):
+            self.cached_results[pos] = self._decide(st[i], self._state.shapes[i])
+
+    def update_references(self, squares_dict):
+        """piece_detector.py:447-453"""
+        self._load_state(squares_dict)
+        self._state.set_ref(list(squares_dict.keys()))
+        self.reference_squares._mark(squares_dict.keys())
+        self.cached_results.clear()
+
+    def _load_state(self, squares_dict):
+        keys = self._state.keys if (self._state.keys and set(squares_dict.keys()) <= set(self._state.keys)) else None
+        if self._state.load(squares_dict, 5, keys=keys):
+            self.reference_squares.clear()  # geometry changed: device planes were reset
+
+    def _update_history(self, pos, has_piece):
+        history = self.detection_history.setdefault(pos, [])
+        history.append(has_piece)
+        if len(history) > self.history_size:
+            history.pop(0)
+
+    def _get_stable_detection(self, pos):
+        if pos not in self.detection_history:
+            return False
+        history = self.detection_history[pos]
+        if len(history) < 3:
+            return history[-1] if history else False
+        return sum(history) / len(history) >= self.min_presence
+
+    def detect_all_pieces(self, squares_dict, use_smoothing=True, use_delta=True, squares_to_check=None):
+        """piece_detector.py:348-440.  Returns (results, visual_changes)."""
+        results, visual_changes, refresh = {}, set(), []
+        if not squares_dict:
+            return results, visual_changes
+        self._load_state(squares_dict)
+        st = self._state.stats(use_ref=bool(self.reference_squares))
+        for pos in squares_dict:
+            i = self._state.index[pos]
+            s = st[i]
+            shape = self._state.shapes[i]
+            has_changed_visual = pos not in self.reference_squares or (np.float64(s.sad_ref) / s.n) > self.change_threshold
+            if has_changed_visual:
+                visual_changes.add(pos)
+            should_process = squares_to_check is not None and pos in squares_to_check
+            if not should_process and (squares_to_check is None or use_delta):
+                if pos not in self.cached_results or has_changed_visual:
+                    should_process = True
+            if should_process or pos not in self.cached_results:
+                raw_result = self._decide(s, shape)
+                self.cached_results[pos] = raw_result.copy()
+            else:
+                raw_result = self.cached_results[pos].copy()
+            raw_has_piece = raw_result["has_piece"]
+            self._update_history(pos, raw_has_piece)
+            is_stable_update = True
+            if use_smoothing:
+                stable = self._get_stable_detection(pos)
+                raw_result["has_piece"] = stable
+                if raw_has_piece != stable:
+                    is_stable_update = False
+            if should_process and is_stable_update:
+                refresh.append(pos)
+            results[pos] = raw_result
+        if refresh:
+            self._state.set_ref(refresh)
+            self.reference_squares._mark(refresh)
+        return results, visual_changes
+
+    def get_occupied_squares(self, squares_dict, use_smoothing=True):
+        results, _ = self.detect_all_pieces(squares_dict, use_smoothing)
+        return {pos for pos, info in results.items() if info["has_piece"]}
+
+
+PieceDetector = PieceDetectorHIP

@@ -1,0 +1,124 @@
+"""Device-resident batched path: enhance -> warp -> 64-square detect over
+frames that stay in HBM (the composed chain of SURVEY.md §3 D).
+
+One BoardPipeline = one camera stream on one GPU: an input frame ring, the
+per-square temporal state of PieceDetector.detect_all_pieces
+(reference squares, cached raw results, 5-frame history) and the result ring.
+Streams are independent, so N GPUs run N pipelines with no exchange.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+from . import synth as S
+from .board_detection import get_perspective_transform
+from .grid_extractor import GridExtractor, SmartGridExtractor
+
+
+def bits_to_positions(bits, rois_rc):
+    """u64 bitset over roi indices -> {(file, rank)} (a1 = (0,0), row 0 = rank 8)."""
+    return {(c, 7 - r) for i, (r, c) in enumerate(rois_rc) if (bits >> i) & 1}
+
+
+class BoardPipeline:
+    def __init__(self, w, h, max_frames, ctx=None):
+        self.ctx = ctx or N.context()
+        self.w, self.h, self.max_frames = w, h, max_frames
+        hdl = C.c_void_p()
+        self.ctx.check(self.ctx.lib.cbv_pipeline_create(self.ctx.h, w, h, max_frames, C.byref(hdl)))
+        self.h_ = hdl
+        self.rois_rc = []
+        self.board_size = 0
+
+    def close(self):
+        if self.h_:
+            self.ctx.lib.cbv_pipeline_destroy(self.h_)
+            self.h_ = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def configure(self, points, profile=None, grid_lines=None, rot180=False, chunk=0, keep_enhanced=False,
+                  clahe_clip_limit=3.0, tile_grid_size=(8, 8), sharpen_kernel=None, display_size=(1280, 720), margin=100,
+                  history_size=5, min_presence=0.6, change_threshold=25):
+        cfg = N.PipelineConfig()
+        e = cfg.enhance
+        e.profile = N.ColorProfile.from_dict(profile)
+        e.clahe_clip_limit = clahe_clip_limit
+        e.tiles_x, e.tiles_y = tile_grid_size
+        e.bilateral_d, e.sigma_color, e.sigma_space = 9, 75.0, 75.0
+        k = np.asarray(sharpen_kernel if sharpen_kernel is not None else [[-1, -1, -1], [-1, 9, -1], [-1, -1, -1]],
+                       dtype=np.float32).reshape(9)
+        for i in range(9):
+            e.sharpen_kernel[i] = float(k[i])
+        S_ = min(display_size) - margin
+        M = get_perspective_transform(np.float32(points), np.float32([[0, 0], [S_, 0], [0, S_], [S_, S_]]))
+        for i in range(9):
+            cfg.M[i] = float(M.reshape(9)[i])
+        cfg.board_size, cfg.rot180 = S_, 1 if rot180 else 0
+        if grid_lines is not None:
+            ge = SmartGridExtractor()
+            ge.grid_lines_x, ge.grid_lines_y = list(grid_lines[0]), list(grid_lines[1])
+        else:
+            ge = GridExtractor()
+        table = ge.roi_table(S_, S_)
+        cfg.n_rois = len(table)
+        self.rois_rc = []
+        for i, (r, c, x0, y0, w, h) in enumerate(table):
+            cfg.rois[i].x0, cfg.rois[i].y0, cfg.rois[i].w, cfg.rois[i].h = x0, y0, w, h
+            self.rois_rc.append((r, c))
+        cfg.history_size, cfg.min_presence, cfg.change_threshold = history_size, min_presence, change_threshold
+        cfg.chunk, cfg.keep_enhanced = chunk, 1 if keep_enhanced else 0
+        self.ctx.check(self.ctx.lib.cbv_pipeline_configure(self.h_, cfg))
+        self.board_size = S_
+        self.matrix = M
+        self._cfg = cfg
+
+    def frames_ptr(self):
+        return self.ctx.lib.cbv_pipeline_frames_dev(self.h_)
+
+    def upload(self, slot, frame):
+        f = N.as_bgr(frame)
+        assert f.shape[:2] == (self.h, self.w)
+        self.ctx.check(self.ctx.lib.cbv_pipeline_upload(self.h_, slot, N.ptr(f), f.strides[0]))
+
+    def synth(self, slot0, count, stream_id=0, frame0=0, scene="normal", frames_per_ply=32, points=None):
+        """Fill slots with synthetic frames of stream `stream_id`, frame indices
+        frame0.. (scripted game, one ply every `frames_per_ply` frames)."""
+        pts = points if points is not None else S.scaled_corners(self.w, self.h)
+        Hinv = np.ascontiguousarray(get_perspective_transform(pts, S.BOARD_UNIT_QUAD).reshape(9))
+        seeds = np.array([S.frame_seed(stream_id, frame0 + i) for i in range(count)], dtype=np.uint64)
+        boards = np.concatenate([S.board_array(S.position_for_frame(frame0 + i, frames_per_ply)) for i in range(count)])
+        boards = np.ascontiguousarray(boards, dtype=np.uint8)
+        sc = N.Scene.from_dict(S.SCENES[scene]) if isinstance(scene, str) else scene
+        self.ctx.check(self.ctx.lib.cbv_pipeline_synth(self.h_, slot0, count, N.ptr(seeds), N.ptr(Hinv), N.ptr(boards), sc))
+
+    def reset_state(self):
+        self.ctx.check(self.ctx.lib.cbv_pipeline_reset_state(self.h_))
+
+    def run(self, slot0, count):
+        """Asynchronous on the context's stream."""
+        self.ctx.check(self.ctx.lib.cbv_pipeline_run(self.h_, slot0, count))
+
+    def results(self, slot0, count):
+        out = (N.FrameResult * count)()
+        self.ctx.check(self.ctx.lib.cbv_pipeline_results(self.h_, slot0, count, out))
+        return out
+
+    def download(self, which, slot):
+        shape = (self.h, self.w, 3) if which in (0, 1) else (self.board_size, self.board_size, 3)
+        out = np.empty(shape, np.uint8)
+        self.ctx.check(self.ctx.lib.cbv_pipeline_download(self.h_, which, slot, N.ptr(out)))
+        return out
+
+    def square_stats(self, slot):
+        out = (N.SqStats * len(self.rois_rc))()
+        self.ctx.check(self.ctx.lib.cbv_pipeline_square_stats(self.h_, slot, out))
+        return out
+
+    def occupied(self, result, stable=True):
+        return bits_to_positions(result.stable_occupied if stable else result.raw_occupied, self.rois_rc)

@@ -1,0 +1,246 @@
+/*
+ * cbv.h — C-ABI of libcbv_hip.so: the MI355X (gfx950) implementation of the
+ * per-frame digitisation path of hericmr/chessboard-vision.
+ *
+ * This is the drop-in boundary.  Every entry point replaces one cv2/numpy
+ * call sequence of the reference (cited as reference file:line); the Python
+ * classes in chessboard-vision_amd/ bind them with ctypes and mirror the
+ * reference's class surface (ImageEnhancer, warp_image, ChangeDetector,
+ * PieceDetector).  Plain pointers and sizes only; no torch types.
+ *
+ * Conventions
+ *   - every function returns CBV_OK (0) or a negative CBV_ERR_* code; the
+ *     message is available from cbv_last_error().
+ *   - images are uint8, HWC, BGR, row stride in bytes given explicitly
+ *     (numpy frames from cv2.VideoCapture; views into them are fine).
+ *   - "host" entry points copy in, run the kernels, copy out and synchronise;
+ *     the library keeps no host pointer after returning.
+ *   - "dev" entry points take device pointers, enqueue on the context's
+ *     stream and do not synchronise.
+ *   - one cbv_ctx per GPU; a ctx is not thread-safe.
+ *   - there is no CPU fallback: without a usable gfx950 device
+ *     cbv_ctx_create() fails with CBV_ERR_NODEV.
+ */
+#ifndef CBV_H
+#define CBV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define CBV_API __attribute__((visibility("default")))
+#else
+#define CBV_API
+#endif
+
+#define CBV_OK 0
+#define CBV_ERR_ARG (-1)
+#define CBV_ERR_HIP (-2)
+#define CBV_ERR_NODEV (-3)
+#define CBV_ERR_STATE (-4)
+#define CBV_ERR_UNSUPPORTED (-5)
+
+#define CBV_MAX_SQUARES 64
+#define CBV_MAX_SQUARE_DIM 128
+
+typedef struct cbv_ctx cbv_ctx;
+typedef struct cbv_squares cbv_squares;
+typedef struct cbv_pipeline cbv_pipeline;
+
+/* color_profile.json as read by ImageEnhancer.load_profile
+ * (frame_enhancer.py:46-54,61-68).  enabled = 0 is the `{}` profile. */
+typedef struct {
+    double hue_shift, sat_scale, val_scale, contrast, brightness;
+    int32_t radical_mode;
+    double target_hue, hue_window;
+    int32_t enabled;
+} cbv_color_profile;
+
+/* Parameters of ImageEnhancer.process_pipeline (frame_enhancer.py:28-44,161-181). */
+typedef struct {
+    cbv_color_profile profile;
+    double clahe_clip_limit;       /* 3.0 */
+    int32_t tiles_x, tiles_y;      /* (8, 8) */
+    int32_t bilateral_d;           /* 9 */
+    double sigma_color, sigma_space; /* 75, 75 */
+    float sharpen_kernel[9];       /* [[-1,-1,-1],[-1,9,-1],[-1,-1,-1]] */
+} cbv_enhance_params;
+
+typedef struct {
+    int32_t x0, y0, w, h;
+} cbv_roi;
+
+/* One square handed over by the host: a (possibly strided) view, 1 or 3 channels. */
+typedef struct {
+    const uint8_t* data;
+    int32_t w, h, stride, cn;
+} cbv_square_view;
+
+/* Integer statistics of one preprocessed (gray + Gaussian-blurred) square.
+ * Everything the host decision chains of PieceDetector.detect_piece
+ * (piece_detector.py:272-345) and ChangeDetector.detect_changes_detailed
+ * (change_detector.py:105-167) need. */
+typedef struct {
+    uint32_t n;                 /* pixels */
+    uint32_t sum, sumsq;        /* sum g, sum g^2  -> np.std (piece_detector.py:305) */
+    uint32_t sad_ref;           /* sum |g - ref|   -> _has_changed (piece_detector.py:90-93) */
+    uint32_t center_sum, center_cnt, border_sum, border_cnt; /* piece_detector.py:177-207 */
+    uint32_t ring_sum[4], ring_cnt[4];                       /* piece_detector.py:141-175 */
+    uint32_t z_count;           /* #(z > z_threshold)  (change_detector.py:136-137) */
+    float z_max;                /* np.max(z)           (change_detector.py:160) */
+} cbv_sq_stats;
+
+/* Synthetic scene (bench / tests only; see chessboard-vision_amd/synth.py). */
+typedef struct {
+    uint8_t bg_lo, bg_span;
+    uint8_t light[3], dark[3], white[3], black[3];
+    uint8_t noise;
+    uint8_t pad[3];
+    double radius;
+} cbv_scene;
+
+/* ------------------------------------------------------------------ */
+/* context                                                             */
+/* ------------------------------------------------------------------ */
+CBV_API int cbv_device_count(void);
+CBV_API int cbv_ctx_create(int device_id, cbv_ctx** out);
+CBV_API void cbv_ctx_destroy(cbv_ctx* ctx);
+/* ctx may be NULL: last error of a failed cbv_ctx_create / host-only call. */
+CBV_API const char* cbv_last_error(const cbv_ctx* ctx);
+/* Launch on a caller-owned hipStream_t (e.g. torch's current stream); NULL
+ * restores the context's own stream. */
+CBV_API int cbv_ctx_set_stream(cbv_ctx* ctx, void* hip_stream);
+CBV_API int cbv_ctx_synchronize(cbv_ctx* ctx);
+CBV_API const char* cbv_device_name(const cbv_ctx* ctx);
+
+/* Per-kernel timing with HIP events on the launch stream.  While enabled,
+ * every launch of kernel `kid` (CBV_K_*) is bracketed by an event pair;
+ * cbv_profile_read synchronises and returns the accumulated time. */
+enum {
+    CBV_K_COLOR_LAB_HIST = 0, CBV_K_CLAHE_LUT, CBV_K_CLAHE_APPLY, CBV_K_BILATERAL, CBV_K_SHARPEN,
+    CBV_K_NORM_LUT, CBV_K_NORMALIZE, CBV_K_WARP, CBV_K_SQUARES, CBV_K_GRAY_BLUR, CBV_K_OTSU,
+    CBV_K_THRESHOLD, CBV_K_SCAN, CBV_K_SYNTH, CBV_K_RESET, CBV_K_COUNT
+};
+CBV_API int cbv_profile_enable(cbv_ctx* ctx, int kid /* -1 = all, -2 = none */);
+CBV_API int cbv_profile_read(cbv_ctx* ctx, int kid, double* total_ms, long long* launches);
+CBV_API int cbv_profile_reset(cbv_ctx* ctx);
+CBV_API const char* cbv_kernel_name(int kid);
+
+/* ------------------------------------------------------------------ */
+/* ImageEnhancer stages, host buffers (frame_enhancer.py)              */
+/* ------------------------------------------------------------------ */
+/* apply_color_profile, frame_enhancer.py:56-99 */
+CBV_API int cbv_apply_color_profile(cbv_ctx* ctx, const uint8_t* bgr, int w, int h, int stride,
+                            const cbv_color_profile* profile, uint8_t* out, int out_stride);
+/* correct_lighting, frame_enhancer.py:101-120 */
+CBV_API int cbv_correct_lighting(cbv_ctx* ctx, const uint8_t* bgr, int w, int h, int stride, double clip_limit,
+                         int tiles_x, int tiles_y, uint8_t* out, int out_stride);
+/* reduce_noise, frame_enhancer.py:122-131 */
+CBV_API int cbv_reduce_noise(cbv_ctx* ctx, const uint8_t* bgr, int w, int h, int stride, int d, double sigma_color,
+                     double sigma_space, uint8_t* out, int out_stride);
+/* sharpen, frame_enhancer.py:133-138 (any 3x3 float kernel) */
+CBV_API int cbv_sharpen(cbv_ctx* ctx, const uint8_t* bgr, int w, int h, int stride, const float* kernel9, uint8_t* out,
+                int out_stride);
+/* normalize_intensity, frame_enhancer.py:140-146 */
+CBV_API int cbv_normalize_intensity(cbv_ctx* ctx, const uint8_t* bgr, int w, int h, int stride, uint8_t* out,
+                            int out_stride);
+/* prepare_analysis, frame_enhancer.py:148-159: returns unblurred gray and Otsu binary */
+CBV_API int cbv_prepare_analysis(cbv_ctx* ctx, const uint8_t* bgr, int w, int h, int stride, uint8_t* gray,
+                         int gray_stride, uint8_t* binary, int binary_stride, int* otsu_threshold);
+/* process_pipeline, frame_enhancer.py:161-181 */
+CBV_API int cbv_process_pipeline(cbv_ctx* ctx, const uint8_t* bgr, int w, int h, int stride,
+                         const cbv_enhance_params* params, uint8_t* out, int out_stride);
+
+/* ------------------------------------------------------------------ */
+/* warp (board_detection.py:61-71, game_session.py:124-126)            */
+/* ------------------------------------------------------------------ */
+/* cv2.getPerspectiveTransform: host-only, 4 (x,y) float32 pairs each. */
+CBV_API int cbv_get_perspective_transform(const float* src8, const float* dst8, double* M9);
+/* cv2.warpPerspective(img, M, (dw, dh)) INTER_LINEAR / BORDER_CONSTANT 0,
+ * optionally followed by cv2.rotate(ROTATE_180). */
+CBV_API int cbv_warp_perspective(cbv_ctx* ctx, const uint8_t* bgr, int w, int h, int stride, const double* M9, int dw,
+                         int dh, int rot180, uint8_t* out, int out_stride);
+
+/* ------------------------------------------------------------------ */
+/* per-square detector state (change_detector.py, piece_detector.py)   */
+/* ------------------------------------------------------------------ */
+CBV_API int cbv_squares_create(cbv_ctx* ctx, cbv_squares** out);
+CBV_API void cbv_squares_destroy(cbv_squares* sq);
+/* _preprocess / _preprocess_square of n squares (change_detector.py:49-56,
+ * piece_detector.py:124-135): upload the views, BGR2GRAY when cn == 3,
+ * GaussianBlur((k,k),0) per square.  Defines the squares' geometry; the
+ * result becomes the "current" gray of each square on the device.  A view
+ * whose data is NULL keeps that square's current gray (subset updates). */
+CBV_API int cbv_squares_load(cbv_squares* sq, const cbv_square_view* views, int n, int blur_k);
+/* Same, reading the ROIs from a device-resident image. */
+CBV_API int cbv_squares_load_dev(cbv_squares* sq, const void* dev_img, int w, int h, int stride, int cn,
+                         const cbv_roi* rois, int n, int blur_k);
+/* calibrate (change_detector.py:36-47): mean = gray, var = initial_variance, for selected squares */
+CBV_API int cbv_squares_calibrate(cbv_squares* sq, double initial_variance, const uint8_t* select /* n flags or NULL */);
+/* update_all_references EMA (change_detector.py:73-92) */
+CBV_API int cbv_squares_ema(cbv_squares* sq, double alpha, const uint8_t* select);
+/* reference_squares[pos] = gray.copy() (piece_detector.py:95-97) */
+CBV_API int cbv_squares_set_ref(cbv_squares* sq, const uint8_t* select);
+/* statistics of the current gray of every square; use_ref / use_model say
+ * whether sad_ref / z_* are wanted (they need set_ref / calibrate first). */
+CBV_API int cbv_squares_stats(cbv_squares* sq, int use_ref, int use_model, double z_threshold, cbv_sq_stats* out);
+/* download / upload per-square planes (tight w*h): which = 0 gray(u8) 1 ref(u8) 2 mean(f32) 3 var(f32) */
+CBV_API int cbv_squares_get(cbv_squares* sq, int which, int index, void* out);
+CBV_API int cbv_squares_set(cbv_squares* sq, int which, int index, const void* in);
+CBV_API int cbv_squares_geometry(cbv_squares* sq, int index, int* w, int* h);
+
+/* ------------------------------------------------------------------ */
+/* device-resident batched pipeline: enhance -> warp -> 64-square detect */
+/* over frames that stay in HBM (bench configs C2..C5)                  */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    cbv_enhance_params enhance;
+    double M[9];                 /* getPerspectiveTransform result */
+    int32_t board_size;          /* 620 */
+    int32_t rot180;
+    int32_t n_rois;              /* 64 */
+    cbv_roi rois[CBV_MAX_SQUARES];   /* index = 8*row + col of the warped image (row 0 = rank 8) */
+    int32_t history_size;        /* 5   piece_detector.py:40 */
+    double min_presence;         /* 0.6 piece_detector.py:41 */
+    double change_threshold;     /* 25  piece_detector.py:50 */
+    int32_t chunk;               /* frames per kernel launch (0 = default) */
+    int32_t keep_enhanced;       /* 1: materialise process_pipeline's output per frame (cbv_pipeline_download
+                                    which = 1); 0: fold the final normalize into the warp gather */
+} cbv_pipeline_config;
+
+/* Per frame result of PieceDetector.detect_all_pieces(use_smoothing=True,
+ * use_delta=True, squares_to_check=None) (piece_detector.py:348-440);
+ * bit i = roi i. */
+typedef struct {
+    uint64_t raw_occupied;     /* raw has_piece per square (cached result when not processed) */
+    uint64_t stable_occupied;  /* after 5-frame smoothing = results[pos]['has_piece'] */
+    uint64_t visual_changes;   /* _has_changed */
+    uint64_t processed;        /* should_process */
+} cbv_frame_result;
+
+CBV_API int cbv_pipeline_create(cbv_ctx* ctx, int w, int h, int max_frames, cbv_pipeline** out);
+CBV_API void cbv_pipeline_destroy(cbv_pipeline* p);
+CBV_API int cbv_pipeline_configure(cbv_pipeline* p, const cbv_pipeline_config* cfg);
+/* device pointer of the input frame ring: [max_frames][h][w][3] uint8 */
+CBV_API void* cbv_pipeline_frames_dev(cbv_pipeline* p);
+CBV_API int cbv_pipeline_upload(cbv_pipeline* p, int slot, const uint8_t* bgr, int stride);
+/* fill slots with synthetic frames generated on the device */
+CBV_API int cbv_pipeline_synth(cbv_pipeline* p, int slot0, int count, const uint64_t* seeds, const double* Hinv9,
+                       const uint8_t* boards /* count*64 */, const cbv_scene* scene);
+/* reset the temporal detector state (reference squares, cache, history) */
+CBV_API int cbv_pipeline_reset_state(cbv_pipeline* p);
+/* enqueue enhance -> warp -> detect for frames [slot0, slot0+count) in stream order; asynchronous */
+CBV_API int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count);
+CBV_API int cbv_pipeline_results(cbv_pipeline* p, int slot0, int count, cbv_frame_result* out);
+/* download intermediates of one slot for parity checks: which = 0 input, 1 enhanced, 2 warped */
+CBV_API int cbv_pipeline_download(cbv_pipeline* p, int which, int slot, uint8_t* out);
+CBV_API int cbv_pipeline_square_stats(cbv_pipeline* p, int slot, cbv_sq_stats* out /* n_rois */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CBV_H */

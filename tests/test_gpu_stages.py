@@ -1,0 +1,295 @@
+"""GPU parity, stage by stage: every ImageEnhancer method, warp and the two
+detectors through the C-ABI against the CPU oracle on the same inputs.
+Bar: bit-exact (the float stages are specified one-rounding-per-op on both
+sides), so the tolerance written here is 0."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from chessboard_vision_amd import synth as S
+from helpers import oracle_frame, random_frame
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def enh(gpu_ctx, tmp_path_factory):
+    from chessboard_vision_amd.frame_enhancer import ImageEnhancer
+    cwd = os.getcwd()
+    os.chdir(tmp_path_factory.mktemp("noprofile"))  # no color_profile.json in cwd
+    e = ImageEnhancer()
+    os.chdir(cwd)
+    assert e.profile == {}
+    return e
+
+
+def assert_same(a, b, what):
+    assert a.shape == b.shape and a.dtype == b.dtype, what
+    if not np.array_equal(a, b):
+        d = np.abs(a.astype(int) - b.astype(int))
+        idx = np.unravel_index(np.argmax(d), d.shape)
+        raise AssertionError("%s: %d of %d values differ, max |diff| %d at %s (gpu %d, oracle %d)"
+                             % (what, int((d > 0).sum()), d.size, int(d.max()), idx, a[idx], b[idx]))
+
+
+FRAMES = {
+    "smooth_640x480": lambda: random_frame(640, 480, 1),
+    "noise_200x120": lambda: random_frame(200, 120, 2, smooth=False),
+    "odd_317x203": lambda: random_frame(317, 203, 3),
+    "synth_normal_640x480": lambda: oracle_frame(640, 480, "normal"),
+    "synth_dim_640x480": lambda: oracle_frame(640, 480, "dim"),
+}
+
+PROFILES = {
+    "shipped": S.SHIPPED_PROFILE,
+    "radical": {"hue_shift": 17, "sat_scale": 1.3, "val_scale": 0.8, "contrast": 0.9, "brightness": 12, "radical_mode": 1,
+                "target_hue": 100, "hue_window": 30},
+    "fractional": {"hue_shift": -200.5, "sat_scale": 0.33, "val_scale": 1.01, "contrast": 2.5, "brightness": -140.25},
+}
+
+
+@pytest.mark.parametrize("fname", list(FRAMES))
+@pytest.mark.parametrize("pname", list(PROFILES))
+def test_apply_color_profile(enh, oracle, fname, pname):
+    f = FRAMES[fname]()
+    enh.profile = PROFILES[pname]
+    try:
+        assert_same(enh.apply_color_profile(f), oracle.apply_color_profile(f, PROFILES[pname]), "apply_color_profile")
+    finally:
+        enh.profile = {}
+
+
+def test_apply_color_profile_empty_is_identity(enh):
+    f = FRAMES["noise_200x120"]()
+    assert enh.apply_color_profile(f) is f  # frame_enhancer.py:57-58 returns the frame itself
+
+
+@pytest.mark.parametrize("fname", list(FRAMES))
+def test_correct_lighting(enh, oracle, fname):
+    f = FRAMES[fname]()
+    assert_same(enh.correct_lighting(f), oracle.correct_lighting(f), "correct_lighting")
+
+
+def test_correct_lighting_other_grid(gpu_ctx, oracle):
+    from chessboard_vision_amd.frame_enhancer import ImageEnhancer
+    e = ImageEnhancer(clahe_clip_limit=1.5, tile_grid_size=(4, 6))
+    e.profile = {}
+    f = random_frame(360, 240, 9)
+    assert_same(e.correct_lighting(f), oracle.correct_lighting(f, 1.5, (4, 6)), "correct_lighting 4x6")
+
+
+@pytest.mark.parametrize("fname", list(FRAMES))
+def test_reduce_noise(enh, oracle, fname):
+    f = FRAMES[fname]()
+    assert_same(enh.reduce_noise(f), oracle.bilateral(f), "reduce_noise")
+
+
+@pytest.mark.parametrize("fname", list(FRAMES))
+def test_sharpen(enh, oracle, fname):
+    f = FRAMES[fname]()
+    assert_same(enh.sharpen(f), oracle.filter3x3(f), "sharpen")
+
+
+def test_sharpen_float_kernel(enh, oracle):
+    f = FRAMES["smooth_640x480"]()
+    k = np.array([[0.0625, 0.125, 0.0625], [0.125, 0.25, 0.125], [0.0625, 0.125, 0.0625]], np.float32)
+    old = enh.sharpen_kernel
+    enh.sharpen_kernel = k
+    try:
+        assert_same(enh.sharpen(f), oracle.filter3x3(f, k), "sharpen(float kernel)")
+    finally:
+        enh.sharpen_kernel = old
+
+
+@pytest.mark.parametrize("fname", list(FRAMES))
+def test_normalize(enh, oracle, fname):
+    f = FRAMES[fname]()
+    f = (f // 2 + 40).astype(np.uint8)  # leave head-room so the stretch does something
+    assert_same(enh.normalize_intensity(f), oracle.normalize_minmax(f), "normalize_intensity")
+
+
+def test_normalize_flat(enh, oracle):
+    f = np.full((64, 80, 3), 77, np.uint8)
+    out = enh.normalize_intensity(f)
+    assert_same(out, oracle.normalize_minmax(f), "normalize flat")
+    assert out.max() == 0
+
+
+@pytest.mark.parametrize("fname", list(FRAMES))
+def test_prepare_analysis(enh, oracle, fname):
+    f = FRAMES[fname]()
+    gray, binary = enh.prepare_analysis(f)
+    og, ob, _ = oracle.prepare_analysis(f)
+    assert_same(gray, og, "prepare_analysis gray")
+    assert_same(binary, ob, "prepare_analysis binary")
+
+
+@pytest.mark.parametrize("fname,pname", [("synth_normal_640x480", None), ("synth_dim_640x480", "shipped"),
+                                         ("odd_317x203", "radical"), ("smooth_640x480", "shipped")])
+def test_process_pipeline(enh, oracle, fname, pname):
+    f = FRAMES[fname]()
+    prof = PROFILES[pname] if pname else {}
+    enh.profile = prof
+    try:
+        assert_same(enh.process_pipeline(f), oracle.process_pipeline(f, prof), "process_pipeline")
+    finally:
+        enh.profile = {}
+
+
+def test_process_pipeline_1080p(enh, oracle):
+    f = oracle_frame(1920, 1080, "dim")
+    enh.profile = S.SHIPPED_PROFILE
+    try:
+        assert_same(enh.process_pipeline(f), oracle.process_pipeline(f, S.SHIPPED_PROFILE), "process_pipeline 1080p")
+    finally:
+        enh.profile = {}
+
+
+def test_process_pipeline_view_input(enh, oracle):
+    big = random_frame(400, 300, 5)
+    view = big[10:250, 20:340]  # strided rows
+    assert_same(enh.process_pipeline(view), oracle.process_pipeline(np.ascontiguousarray(view), {}), "pipeline(view)")
+
+
+# ---------------------------------------------------------------------------
+def test_perspective_transform_matches_oracle(oracle):
+    from chessboard_vision_amd.board_detection import get_perspective_transform
+    for pts in (S.scaled_corners(1920, 1080), S.scaled_corners(640, 480), np.float32([[3, 7], [500, -20], [-40, 610], [700, 650]])):
+        dst = np.float32([[0, 0], [620, 0], [0, 620], [620, 620]])
+        assert np.array_equal(get_perspective_transform(pts, dst), oracle.get_perspective_transform(pts, dst))
+
+
+@pytest.mark.parametrize("size", [(1920, 1080), (640, 480)])
+def test_warp_image(gpu_ctx, oracle, size):
+    from chessboard_vision_amd.board_detection import warp_image
+    f = oracle_frame(size[0], size[1], "normal")
+    pts = S.scaled_corners(*size)
+    w, M, bs = warp_image(f, pts)
+    ow, oM, obs = oracle.warp_image(f, pts)
+    assert bs == obs == 620
+    assert np.array_equal(M, oM)
+    assert_same(w, ow, "warp_image")
+
+
+def test_warp_border_and_rot180(gpu_ctx, oracle):
+    from chessboard_vision_amd.board_detection import get_perspective_transform, warp_perspective
+    f = random_frame(320, 240, 11)
+    pts = np.float32([[-30, -20], [350, 10], [5, 260], [300, 230]])  # quad partly outside the frame
+    M = get_perspective_transform(pts, np.float32([[0, 0], [620, 0], [0, 620], [620, 620]]))
+    ow = oracle.warp_perspective(f, M, (620, 620))
+    assert (ow == 0).any()
+    assert_same(warp_perspective(f, M, (620, 620)), ow, "warp with border")
+    assert_same(warp_perspective(f, M, (620, 620), rot180=True), oracle.rotate180(ow), "warp + rotate180")
+    assert_same(warp_perspective(f, M, (200, 90)), oracle.warp_perspective(f, M, (200, 90)), "warp small dst")
+
+
+# ---------------------------------------------------------------------------
+def test_reference_regression_case(gpu_ctx):
+    """The reference's own test_change_detector_regression.py:31-54."""
+    from chessboard_vision_amd.change_detector import ChangeDetector
+    det = ChangeDetector()
+    squares = {(c, r): np.zeros((50, 50), np.uint8) for r in range(8) for c in range(8)}
+    det.calibrate(squares)
+    assert det.is_calibrated
+    squares[(3, 3)] = np.full((50, 50), 255, np.uint8)
+    changes = det.detect_changes(squares)
+    assert (3, 3) in changes and changes[(3, 3)] > 50.0
+    detailed = det.detect_changes_detailed(squares)
+    assert detailed[(3, 3)]["intensity"] == "TOTAL"
+    assert detailed[(3, 3)]["pct_changed"] == 100.0 and detailed[(3, 3)]["z_score"] == 25.5
+    assert detailed[(3, 3)]["is_circular"] is False  # std 0 < 15
+    assert set(detailed) == {(3, 3)}
+
+
+def test_reference_regression_calibration_noise(gpu_ctx):
+    """test_change_detector_regression.py:19-29"""
+    from chessboard_vision_amd.change_detector import ChangeDetector
+    rng = np.random.default_rng(0)
+    det = ChangeDetector()
+    det.calibrate({(c, r): rng.integers(0, 255, (50, 50), dtype=np.uint8) for r in range(8) for c in range(8)})
+    assert det.is_calibrated and len(det.means) == 64 and det.means[(0, 0)].dtype == np.float32
+
+
+def _board_squares(oracle, frame_idx, scene="normal", grid="linear"):
+    from chessboard_vision_amd.grid_extractor import GridExtractor, SmartGridExtractor
+    f = oracle_frame(640, 480, scene, frame_idx=frame_idx, frames_per_ply=2)
+    warped, _, _ = oracle.warp_image(f, S.scaled_corners(640, 480))
+    if grid == "linear":
+        return GridExtractor().split_board(warped)
+    g = SmartGridExtractor()
+    g.grid_lines_x, g.grid_lines_y = list(S.CALIB_GRID_X), list(S.CALIB_GRID_Y)
+    return g.split_board(warped)
+
+
+@pytest.mark.parametrize("grid", ["linear", "smart"])
+def test_piece_detector_sequence(gpu_ctx, oracle, grid):
+    from chessboard_vision_amd.piece_detector import PieceDetector
+    from ref_logic import RefPieceDetector
+    gpu, ref = PieceDetector(), RefPieceDetector()
+    sq0 = _board_squares(oracle, 0, grid=grid)
+    gpu.update_references(sq0)
+    ref.update_references(sq0)
+    for t in range(0, 14):
+        sq = _board_squares(oracle, t, grid=grid)
+        check = None if t % 3 else {(4, 1), (4, 3), (0, 0)}
+        r1, v1 = gpu.detect_all_pieces(sq, squares_to_check=check)
+        r2, v2 = ref.detect_all_pieces(sq, squares_to_check=check)
+        assert v1 == v2, "visual_changes differ at frame %d" % t
+        assert r1.keys() == r2.keys()
+        for pos in r1:
+            assert r1[pos] == r2[pos], (t, pos, r1[pos], r2[pos])
+        for pos in sq:
+            assert np.array_equal(gpu.reference_squares[pos], ref.reference_squares[pos]), (t, pos)
+    occ = {p for p, r in r1.items() if r["has_piece"]}
+    assert occ == set(S.position_for_frame(13, 2).keys())
+
+
+def test_change_detector_sequence(gpu_ctx, oracle):
+    from chessboard_vision_amd.change_detector import ChangeDetector
+    from ref_logic import RefChangeDetector
+    gpu, ref = ChangeDetector(), RefChangeDetector()
+    for blur in (5, 13, 1):
+        gpu.blur_kernel = ref.blur_kernel = blur
+        gpu.z_threshold = ref.z_threshold = 2.55
+        gpu.initial_variance = ref.initial_variance = 600
+        gpu.alpha = ref.alpha = 0.13
+        sq0 = _board_squares(oracle, 0)
+        gpu.calibrate(sq0)
+        ref.calibrate(sq0)
+        for t in range(1, 8):
+            sq = _board_squares(oracle, t)
+            d1, d2 = gpu.detect_changes_detailed(sq), ref.detect_changes_detailed(sq)
+            assert d1 == d2, (blur, t)
+            if t == 4:
+                gpu.set_focus_squares([(4, 1), (4, 3)])
+                ref.focus_squares = {(4, 1), (4, 3)}
+            gpu.update_all_references(sq)
+            ref.update_all_references(sq)
+            for pos in sq:
+                assert np.array_equal(gpu.means[pos], ref.means[pos]), (blur, t, pos)
+                assert np.array_equal(gpu.variances[pos], ref.variances[pos]), (blur, t, pos)
+        gpu.clear_focus()
+        ref.focus_squares = set()
+
+
+def test_squares_edge_shapes(gpu_ctx, oracle):
+    """ragged / tiny / maximum-size squares, gray and BGR."""
+    from chessboard_vision_amd._squares import GRAY, SquareSet
+    rng = np.random.default_rng(4)
+    shapes = [(128, 128, 3), (1, 1), (5, 7, 3), (77, 80), (3, 128, 3), (128, 2)]
+    sq = {i: rng.integers(0, 256, size=s, dtype=np.uint8) for i, s in enumerate(shapes)}
+    for k in (5, 3, 9, 15):
+        ss = SquareSet()
+        ss.load(sq, k)
+        st = ss.stats()
+        for i in sq:
+            og = oracle.square_preprocess(sq[i], k)
+            assert np.array_equal(ss.get(GRAY, i), og), (k, i)
+            ost = oracle.square_stats(og)
+            for fld in ("n", "sum", "sumsq", "center_sum", "center_cnt", "border_sum", "border_cnt"):
+                assert getattr(st[i], fld) == getattr(ost, fld), (k, i, fld)
+            assert list(st[i].ring_sum) == list(ost.ring_sum) and list(st[i].ring_cnt) == list(ost.ring_cnt)
+    with pytest.raises(RuntimeError):
+        SquareSet().load({0: np.zeros((129, 10), np.uint8)}, 5)
