@@ -242,8 +242,9 @@ def test_piece_detector_sequence(gpu_ctx, oracle, grid):
             assert r1[pos] == r2[pos], (t, pos, r1[pos], r2[pos])
         for pos in sq:
             assert np.array_equal(gpu.reference_squares[pos], ref.reference_squares[pos]), (t, pos)
-    occ = {p for p, r in r1.items() if r["has_piece"]}
-    assert occ == set(S.position_for_frame(13, 2).keys())
+        # raw (unsmoothed) occupancy is the scripted position of this frame; the smoothed one lags by design
+        raw = {p for p, r in gpu.cached_results.items() if r["has_piece"]}
+        assert raw == set(S.position_for_frame(t, 2).keys()), t
 
 
 def test_change_detector_sequence(gpu_ctx, oracle):

@@ -1,0 +1,65 @@
+"""N > 1 path of bench.py on CPU: two gloo ranks shard independent streams
+(no data-path collective) and agree on the max-over-ranks time and the
+whole-job throughput."""
+import os
+import socket
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import bench
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = bench.shard_streams(8, world, rank)
+    # per-rank "work": distinct streams, per-rank elapsed time; only the time is reduced (MAX)
+    elapsed = torch.tensor([0.5 + 0.25 * rank], dtype=torch.float64)
+    dist.barrier()
+    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    fps = bench.aggregate_fps(frames_per_rank=512, steps=4, world_size=world, elapsed_max_s=float(elapsed))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    q.put((rank, mine, float(elapsed), fps, gathered))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_shard_streams_and_reduce_time():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, s0, e0, f0, g0), (r1, s1, e1, f1, g1) = out
+    assert s0 == [0, 2, 4, 6] and s1 == [1, 3, 5, 7]          # disjoint, complete
+    assert sorted(g0[0] + g0[1]) == list(range(8))
+    assert e0 == e1 == 0.75                                     # MAX over ranks
+    assert f0 == f1 == 512 * 4 * 2 / 0.75                       # whole-job frames/s
+
+
+def test_algorithmic_bytes_match_survey():
+    sys.path.insert(0, ROOT)
+    import bench
+    per, total = bench.algorithmic_bytes(1920, 1080)
+    assert total == 70649925
+    assert per["k_bilateral"] == 2 * 6220800
+    _, total4k = bench.algorithmic_bytes(3840, 2160)
+    assert abs(total4k - 265479684) <= 16
