@@ -139,6 +139,9 @@ def main():
 
     res = pipe.results(0, F)
     occ_ok = pipe.occupied(res[F - 1]) == set(S.position_for_frame(F - 1).keys())
+    if not occ_ok and rank == 0:
+        got, exp = pipe.occupied(res[F - 1]), set(S.position_for_frame(F - 1).keys())
+        print("occupancy mismatch at frame %d: extra %s missing %s" % (F - 1, sorted(got - exp), sorted(exp - got)), file=sys.stderr)
 
     per_kernel_bytes, path_bytes = algorithmic_bytes(w, h)
     fps = aggregate_fps(F, args.steps, world, elapsed)
