@@ -917,6 +917,9 @@ extern "C" int cbv_pipeline_configure(cbv_pipeline* p, const cbv_pipeline_config
     CBV_HIP(ctx, hipMemcpy(p->d_descs.p, p->descs.data(), sizeof(SquareDesc) * n, hipMemcpyHostToDevice));
     CBV_HIP(ctx, hipMemcpy(p->d_masks.p, masks.data(), off, hipMemcpyHostToDevice));
     CBV_HIP(ctx, hipMemset(p->d_state.p, 0, sizeof(ScanState) * n));
+    // plane padding (planes are rounded to 16 B) must read as zero in every frame: k_scan compares whole vectors
+    CBV_HIP(ctx, hipMemset(p->d_gray.p, 0, off * p->max_frames));
+    CBV_HIP(ctx, hipMemset(p->d_ref.p, 0, off));
     p->configured = true;
     return CBV_OK;
 }

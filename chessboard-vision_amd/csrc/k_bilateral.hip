@@ -1,99 +1,164 @@
 // cv2.bilateralFilter(d, sigmaColor, sigmaSpace) on 8UC3 (frame_enhancer.py:131).
 //
-// VALU-bound stencil (49 taps at d = 9), not an HBM-bound one.  Layout:
-//   - a 64 x 32 pixel tile (+ radius halo, REFLECT_101 at the image border) is
-//     staged in LDS as packed BGRx dwords, so |db|+|dg|+|dr| is ONE v_sad_u8;
-//   - each lane owns a 4-pixel horizontal strip on two rows; for every tap row
-//     it pulls 4+2R packed pixels with aligned ds_read_b128 and converts them
-//     to float once for all four outputs;
-//   - colour weights come from a 768-entry float LUT in LDS, space weights are
-//     wave-uniform scalars;
+// VALU/LDS-bound stencil (49 taps at d = 9), not an HBM-bound one.  Structure:
+//   - persistent workgroups of 1024 lanes (16 waves = 4 per SIMD, <= 128 VGPRs),
+//     one per CU, each walking 64x64-pixel tiles; consecutive tiles of one XCD
+//     are neighbours, so halo rows are re-read from that XCD's L2;
+//   - the tile (+4 px halo, REFLECT_101 at the image border) sits in LDS as
+//     packed BGRx dwords: |db|+|dg|+|dr| is ONE v_sad_u8; the next tile is
+//     prefetched into registers while the current one is filtered;
+//   - the 766-entry colour-weight table is replicated 32x in LDS with the copy
+//     index in the bank bits (entry i of copy c at word 32 i + c, c = lane & 31):
+//     every lane of a half-wave reads its own bank, so the data-dependent
+//     gather is conflict-free (the first version lost 60 % of its LDS cycles to
+//     bank conflicts);
+//   - each lane owns a 4-pixel strip on TWO adjacent rows; per tap row it reads
+//     12 packed pixels with three aligned ds_read_b128 and converts them to
+//     float once for all eight outputs (v_cvt_f32_ubyte is a half-rate op on
+//     gfx950, like v_sad_u8; only f32 add/mul and simple integer ops are full
+//     rate — tools/ubench_valu.hip);
+//   - the LUT address (sad << 7) | (lane & 31) << 2 is ONE v_alignbit_b32;
 //   - taps are accumulated per output in row-major (dy, dx) order with separate
-//     multiply and add (no FMA contraction), which makes the result bit-equal to
-//     the scalar definition of the filter.
+//     multiply and add (no FMA contraction): bit-equal to the scalar definition.
 #include "cbv_device.h"
 
-#define BL_TW 64
-#define BL_TH 32
+#define BL_TW 128        // tile width in pixels (32 strips of 4)
+#define BL_TH 64         // tile height in pixels (32 row pairs: two rows per lane)
+#define BL_HALO 4        // halo in pixels (radius <= 4; 4 keeps ds_read_b128 aligned)
+#define BL_PITCH (BL_TW + 2 * BL_HALO)
+#define BL_THREADS 1024
+#define BL_LUT_WORDS (768 * 32)
 
-template <int R>
-struct BlCfg {
-    static constexpr int HALO_X = 4;                       // halo rounded up to 4 px so b128 reads stay aligned
-    static constexpr int PITCH = BL_TW + 2 * HALO_X;       // pixels (dwords) per LDS row
-    static constexpr int ROWS = BL_TH + 2 * R;
-    static_assert(R <= 4, "radius above 4 needs a wider halo");
-};
-
-template <int R>
-__global__ __launch_bounds__(256) void k_bilateral(const u8* __restrict__ src, u8* __restrict__ dst, Geom g,
-                                                    const BilateralTabs* __restrict__ bt, int tiles_xn, int tiles_n)
+__host__ __device__ constexpr int bl_row_reach(int R, int dy)
 {
-    using C = BlCfg<R>;
-    __shared__ __attribute__((aligned(16))) u32 tile[C::ROWS * C::PITCH];
-    __shared__ float cw[768];
+    int rx = 0;
+    while ((rx + 1) * (rx + 1) + dy * dy <= R * R) rx++;
+    return rx;
+}
 
-    const int tid = xcd_remap(blockIdx.x, tiles_n);
-    const int tyi = tid / tiles_xn, txi = tid - tyi * tiles_xn;
-    const int x0 = txi * BL_TW, y0 = tyi * BL_TH;
-    const size_t fo = (size_t)blockIdx.z * g.frame_stride;
-    const u8* sf = src + fo;
-    u8* df = dst + fo;
+template <int R>
+__global__ __launch_bounds__(BL_THREADS) void k_bilateral(const u8* __restrict__ src, u8* __restrict__ dst, Geom g,
+                                                           const BilateralTabs* __restrict__ bt, int tiles_xn,
+                                                           int tiles_yn, int batch)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    float* cw = (float*)smem;                                   // [768][32]
+    u32* tile = (u32*)(smem + BL_LUT_WORDS * 4);                // [(BL_TH + 2R)][BL_PITCH]
+    float* sw2d = (float*)(tile + (BL_TH + 2 * R) * BL_PITCH);   // [2R+1][9] space weights by (dy, dx)
+    int* reach = (int*)(sw2d + 96);                             // [2R+1] half-width of the disc per row
+    constexpr int ROWS = BL_TH + 2 * R;
+    constexpr int GROUPS = BL_PITCH / 4;                        // 4-pixel groups per tile row
+    constexpr int NG = ROWS * GROUPS;                           // groups per tile (<= 2448)
+    constexpr int GPT = (NG + BL_THREADS - 1) / BL_THREADS;     // groups per thread (3)
 
-    for (int i = threadIdx.x; i < 768; i += blockDim.x) cw[i] = bt->color_w[i];
+    const int tid = threadIdx.x;
+    const int lane32 = tid & 31;
+    for (int i = tid; i < BL_LUT_WORDS; i += BL_THREADS) cw[i] = bt->color_w[i >> 5];
+    if (tid < bt->maxk) sw2d[(bt->dy[tid] + R) * 9 + bt->dx[tid] + R] = bt->space_w[tid];
+    if (tid <= 2 * R) reach[tid] = bl_row_reach(R, tid - R);
 
-    // stage: groups of 4 pixels (12 source bytes -> 4 packed dwords)
+    const int tiles_per_frame = tiles_xn * tiles_yn;
+    const int ntiles = tiles_per_frame * batch;
     const bool aligned = (g.stride & 3) == 0;
-    constexpr int GROUPS = C::PITCH / 4;
-    for (int i = threadIdx.x; i < C::ROWS * GROUPS; i += blockDim.x) {
-        const int r = i / GROUPS, gi = i - r * GROUPS;
-        const int sy = d_reflect101(y0 - R + r, g.h);
-        const int gx = x0 - C::HALO_X + gi * 4;
+
+    // Interior 4-pixel groups are prefetched as 3 raw dwords; groups that touch the image border
+    // (REFLECT_101) are rare and are fetched synchronously, byte-wise, when the tile is written.
+    auto group_origin = [&](int t, int gi, int& f, int& y, int& gx) {
+        f = t / tiles_per_frame;
+        const int tt = t - f * tiles_per_frame;
+        const int tyi = tt / tiles_xn, txi = tt - tyi * tiles_xn;
+        const int r = gi / GROUPS, gc = gi - r * GROUPS;
+        y = tyi * BL_TH - R + r;
+        gx = txi * BL_TW - BL_HALO + gc * 4;
+    };
+    auto prefetch = [&](int t, int gi, u32* d) {
+        int f, y, gx;
+        group_origin(t, gi, f, y, gx);
+        if (aligned && gx >= 0 && gx + 3 < g.w && y >= 0 && y < g.h) {
+            const u32* q = (const u32*)(src + (size_t)f * g.frame_stride + (size_t)y * g.stride + (size_t)gx * 3);
+            d[0] = q[0];
+            d[1] = q[1];
+            d[2] = q[2];
+        }
+    };
+    auto commit = [&](int t, int gi, const u32* d) {
+        int f, y, gx;
+        group_origin(t, gi, f, y, gx);
         u32 p0, p1, p2, p3;
-        if (aligned && gx >= 0 && gx + 3 < g.w) {
-            const u32* p = (const u32*)(sf + (size_t)sy * g.stride + (size_t)gx * 3);
-            u32 d0 = p[0], d1 = p[1], d2 = p[2];
-            p0 = d0 & 0xFFFFFFu;
-            p1 = (d0 >> 24) | ((d1 & 0xFFFFu) << 8);
-            p2 = (d1 >> 16) | ((d2 & 0xFFu) << 16);
-            p3 = d2 >> 8;
+        if (aligned && gx >= 0 && gx + 3 < g.w && y >= 0 && y < g.h) {
+            p0 = d[0] & 0xFFFFFFu;
+            p1 = (d[0] >> 24) | ((d[1] & 0xFFFFu) << 8);
+            p2 = (d[1] >> 16) | ((d[2] & 0xFFu) << 16);
+            p3 = d[2] >> 8;
         } else {
+            const u8* sf = src + (size_t)f * g.frame_stride + (size_t)d_reflect101(y, g.h) * g.stride;
             u32 pp[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const int sx = d_reflect101(gx + k, g.w);
-                const u8* p = sf + (size_t)sy * g.stride + (size_t)sx * 3;
-                pp[k] = (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16);
+                const u8* q = sf + (size_t)d_reflect101(gx + k, g.w) * 3;
+                pp[k] = (u32)q[0] | ((u32)q[1] << 8) | ((u32)q[2] << 16);
             }
             p0 = pp[0];
             p1 = pp[1];
             p2 = pp[2];
             p3 = pp[3];
         }
-        *(uint4*)&tile[r * C::PITCH + gi * 4] = make_uint4(p0, p1, p2, p3);
-    }
-    __syncthreads();
+        const int r = gi / GROUPS, gc = gi - r * GROUPS;
+        *(uint4*)&tile[r * BL_PITCH + gc * 4] = make_uint4(p0, p1, p2, p3);
+    };
 
-    const int sx = threadIdx.x & 15; // strip index: pixels 4*sx .. 4*sx+3
-    const int sy = threadIdx.x >> 4; // rows sy and sy + 16
-    const bool aligned_out = aligned;
-
-#pragma unroll 1
-    for (int half = 0; half < 2; half++) {
-        const int ly = sy + half * 16;
-        const int y = y0 + ly;
-        const int x = x0 + sx * 4;
-        float sb[4], sg[4], sr[4], sw[4];
-        u32 ctr[4];
+    // persistent walk: sequence number s = i * gridDim + block; XCD x owns a contiguous tile range
+    int s = blockIdx.x;
+    u32 pre[GPT][3];
+    if (s < ntiles) {
+        const int t = xcd_remap(s, ntiles);
 #pragma unroll
-        for (int o = 0; o < 4; o++) {
-            sb[o] = sg[o] = sr[o] = sw[o] = 0.f;
-            ctr[o] = tile[(ly + R) * C::PITCH + C::HALO_X + sx * 4 + o];
+        for (int k = 0; k < GPT; k++) {
+            const int gi = tid + k * BL_THREADS;
+            if (gi < NG) prefetch(t, gi, pre[k]);
         }
-        int k = 0; // running tap index (row-major over the disc), compile-time after unrolling
+    }
+    const int sx = tid & 31;  // strip: pixels 4*sx .. 4*sx+3
+    const int ly = (tid >> 5) * 2; // first of the lane's two tile rows
+
+    for (; s < ntiles; s += gridDim.x) {
+        const int t = xcd_remap(s, ntiles);
+        __syncthreads(); // previous tile fully consumed (and the LUT is written on the first pass)
 #pragma unroll
-        for (int dy = -R; dy <= R; dy++) {
-            // packed pixels x-4 .. x+7 of tap row
-            const uint4* rowp = (const uint4*)&tile[(ly + R + dy) * C::PITCH + sx * 4];
+        for (int k = 0; k < GPT; k++) {
+            const int gi = tid + k * BL_THREADS;
+            if (gi < NG) commit(t, gi, pre[k]);
+        }
+        __syncthreads();
+        // prefetch the next tile while this one is filtered
+        const int sn = s + gridDim.x;
+        if (sn < ntiles) {
+            const int tn = xcd_remap(sn, ntiles);
+#pragma unroll
+            for (int k = 0; k < GPT; k++) {
+                const int gi = tid + k * BL_THREADS;
+                if (gi < NG) prefetch(tn, gi, pre[k]);
+            }
+        }
+
+        // outputs: [row a/b][pixel 0..3]
+        float sb[2][4], sg[2][4], sr[2][4], sw[2][4];
+        u32 ctr[2][4];
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                sb[a][o] = sg[a][o] = sr[a][o] = sw[a][o] = 0.f;
+                ctr[a][o] = tile[(ly + a + R) * BL_PITCH + BL_HALO + sx * 4 + o];
+            }
+        const u32 lane_hi = (u32)lane32 << 27; // v_alignbit(sad, lane_hi, 25) = (sad << 7) | (lane32 << 2)
+        // One tile row per iteration, NOT unrolled (a fully unrolled body makes hipcc schedule ~250
+        // live registers).  Tile row ly + i is tap row dy = i - R of output row a and dy = i - 1 - R of
+        // output row b; every output still sees its taps in ascending (dy, dx) order.
+        const u32* rowp0 = &tile[ly * BL_PITCH + sx * 4];
+#pragma unroll 1
+        for (int i = 0; i <= 2 * R + 1; i++) {
+            const uint4* rowp = (const uint4*)(rowp0 + i * BL_PITCH);
             const uint4 q0 = rowp[0], q1 = rowp[1], q2 = rowp[2];
             const u32 p[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
             float fb[12], fg[12], fr[12];
@@ -103,48 +168,58 @@ __global__ __launch_bounds__(256) void k_bilateral(const u8* __restrict__ src, u
                 fg[j] = (float)((p[j] >> 8) & 255u);
                 fr[j] = (float)((p[j] >> 16) & 255u);
             }
-            // taps of this row: |dx| <= floor(sqrt(R^2 - dy^2))  (r = sqrt(i*i + j*j) <= radius)
-            int rx = 0;
-            while ((rx + 1) * (rx + 1) + dy * dy <= R * R) rx++;
 #pragma unroll
-            for (int dx = -R; dx <= R; dx++) {
-                if (dx < -rx || dx > rx) continue;
-                const float spw = bt->space_w[k];
+            for (int a = 0; a < 2; a++) {
+                const int dyi = i - a; // tap-row index of output row a (0 .. 2R), wave-uniform
+                if (dyi < 0 || dyi > 2 * R) continue;
+                const int rx = __builtin_amdgcn_readfirstlane(reach[dyi]);
 #pragma unroll
-                for (int o = 0; o < 4; o++) {
-                    const int j = o + 4 + dx;
-                    const u32 sad = __builtin_amdgcn_sad_u8(p[j], ctr[o], 0u);
-                    const float wgt = spw * cw[sad];
-                    const float tb = fb[j] * wgt, tg = fg[j] * wgt, tr = fr[j] * wgt;
-                    sb[o] = sb[o] + tb;
-                    sg[o] = sg[o] + tg;
-                    sr[o] = sr[o] + tr;
-                    sw[o] = sw[o] + wgt;
+                for (int dx = -R; dx <= R; dx++) {
+                    if (dx < -rx || dx > rx) continue; // scalar branch
+                    const float spw = sw2d[dyi * 9 + dx + R];
+#pragma unroll
+                    for (int o = 0; o < 4; o++) {
+                        const int j = o + 4 + dx;
+                        const u32 sad = __builtin_amdgcn_sad_u8(p[j], ctr[a][o], 0u);
+                        const u32 addr = __builtin_amdgcn_alignbit(sad, lane_hi, 25);
+                        const float wgt = spw * *(const float*)((const u8*)cw + addr);
+                        const float tb = fb[j] * wgt, tg = fg[j] * wgt, tr = fr[j] * wgt;
+                        sb[a][o] = sb[a][o] + tb;
+                        sg[a][o] = sg[a][o] + tg;
+                        sr[a][o] = sr[a][o] + tr;
+                        sw[a][o] = sw[a][o] + wgt;
+                    }
                 }
-                k++;
             }
         }
-        if (y < g.h && x < g.w) {
-            Px4 out;
-            out.d[0] = out.d[1] = out.d[2] = 0;
+        const int f = t / tiles_per_frame, tt = t - f * tiles_per_frame;
+        const int tyi = tt / tiles_xn, txi = tt - tyi * tiles_xn;
+        const int x = txi * BL_TW + sx * 4;
 #pragma unroll
-            for (int o = 0; o < 4; o++) {
-                const float inv = 1.f / sw[o];
-                px_set(out, 3 * o, d_round_f(sb[o] * inv));
-                px_set(out, 3 * o + 1, d_round_f(sg[o] * inv));
-                px_set(out, 3 * o + 2, d_round_f(sr[o] * inv));
-            }
-            u8* q = df + (size_t)y * g.stride + (size_t)x * 3;
-            const int npx = min(4, g.w - x);
-            if (aligned_out && npx == 4) {
-                u32* qw = (u32*)q;
-                qw[0] = out.d[0];
-                qw[1] = out.d[1];
-                qw[2] = out.d[2];
-            } else {
+        for (int a = 0; a < 2; a++) {
+            const int y = tyi * BL_TH + ly + a;
+            if (y < g.h && x < g.w) {
+                Px4 out;
+                out.d[0] = out.d[1] = out.d[2] = 0;
 #pragma unroll
-                for (int j = 0; j < 12; j++)
-                    if (j < npx * 3) q[j] = (u8)px_get(out, j);
+                for (int o = 0; o < 4; o++) {
+                    const float inv = 1.f / sw[a][o];
+                    px_set(out, 3 * o, d_round_f(sb[a][o] * inv));
+                    px_set(out, 3 * o + 1, d_round_f(sg[a][o] * inv));
+                    px_set(out, 3 * o + 2, d_round_f(sr[a][o] * inv));
+                }
+                u8* q = dst + (size_t)f * g.frame_stride + (size_t)y * g.stride + (size_t)x * 3;
+                const int npx = min(4, g.w - x);
+                if (aligned && npx == 4) {
+                    u32* qw = (u32*)q;
+                    qw[0] = out.d[0];
+                    qw[1] = out.d[1];
+                    qw[2] = out.d[2];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 12; j++)
+                        if (j < npx * 3) q[j] = (u8)px_get(out, j);
+                }
             }
         }
     }
@@ -153,10 +228,20 @@ __global__ __launch_bounds__(256) void k_bilateral(const u8* __restrict__ src, u
 template <int R>
 static int launch_bilateral_r(cbv_ctx* ctx, const u8* src, u8* dst, Geom g, int batch)
 {
-    int txn = (g.w + BL_TW - 1) / BL_TW, tyn = (g.h + BL_TH - 1) / BL_TH;
+    const int txn = (g.w + BL_TW - 1) / BL_TW, tyn = (g.h + BL_TH - 1) / BL_TH;
+    const int ntiles = txn * tyn * batch;
+    const size_t lds = (size_t)BL_LUT_WORDS * 4 + (size_t)(BL_TH + 2 * R) * BL_PITCH * 4 + 96 * 4 + 16 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        CBV_HIP(ctx, hipFuncSetAttribute((const void*)k_bilateral<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    int grid = ctx->num_cus < ntiles ? ctx->num_cus : ntiles; // one persistent workgroup per CU
+    grid = (grid + 7) & ~7;                                   // whole XCD groups
+    if (grid > ntiles) grid = ntiles;
     prof_begin(ctx, CBV_K_BILATERAL);
-    hipLaunchKernelGGL(k_bilateral<R>, dim3(txn * tyn, 1, batch), dim3(256), 0, ctx->stream, src, dst, g, ctx->btabs,
-                       txn, txn * tyn);
+    hipLaunchKernelGGL(k_bilateral<R>, dim3(grid), dim3(BL_THREADS), lds, ctx->stream, src, dst, g, ctx->btabs, txn, tyn,
+                       batch);
     prof_end(ctx, CBV_K_BILATERAL);
     CBV_HIP(ctx, hipGetLastError());
     return CBV_OK;

@@ -256,33 +256,56 @@ __device__ bool d_detect_piece(const cbv_sq_stats& st)
 // detect_all_pieces(use_smoothing=True, use_delta=True, squares_to_check=None)
 // (piece_detector.py:348-440) over `count` consecutive frames; one workgroup
 // per square, state carried in ScanState and `ref`.
+// The chain is sequential per square, so the kernel is latency-bound: the
+// square's plane moves as 16-byte vectors (planes are 16-byte aligned and
+// zero-padded), the reference lives in registers, the next frame's plane is
+// prefetched while the current one is reduced, and one barrier per frame
+// (double-buffered partial sums) is all the synchronisation there is.
+#define SCAN_VPT 4 // 16-byte vectors per lane: 256 lanes x 4 x 16 B = 128 x 128 px
 __global__ __launch_bounds__(256) void k_scan(const SquareDesc* __restrict__ descs, ScanParams sp,
                                                const u8* __restrict__ gray, size_t gray_frame_stride,
                                                const cbv_sq_stats* __restrict__ stats, u8* __restrict__ ref,
                                                ScanState* __restrict__ state, cbv_frame_result* __restrict__ results,
                                                int count)
 {
-    extern __shared__ __attribute__((aligned(16))) u8 smem[];
-    __shared__ u32 red[4];
-    __shared__ int flag[1];
+    __shared__ u32 red[2][4];
     const int sq = blockIdx.x;
     const SquareDesc d = descs[sq];
     const int n = d.w * d.h;
-    u8* lref = smem;
+    const int nvec = (n + 15) >> 4;
     ScanState st = state[sq];
-    if (st.has_ref)
-        for (int i = threadIdx.x; i < n; i += blockDim.x) lref[i] = ref[d.plane_off + i];
-    __syncthreads();
+    uint4 rv[SCAN_VPT], cur[SCAN_VPT], nxt[SCAN_VPT];
+    const uint4* refv = (const uint4*)(ref + d.plane_off);
+#pragma unroll
+    for (int k = 0; k < SCAN_VPT; k++) {
+        const int vi = threadIdx.x + k * 256;
+        rv[k] = (st.has_ref && vi < nvec) ? refv[vi] : make_uint4(0, 0, 0, 0);
+        cur[k] = vi < nvec ? ((const uint4*)(gray + d.plane_off))[vi] : make_uint4(0, 0, 0, 0);
+    }
     for (int t = 0; t < count; t++) {
-        const u8* g = gray + (size_t)t * gray_frame_stride + d.plane_off;
+        if (t + 1 < count) {
+            const uint4* gn = (const uint4*)(gray + (size_t)(t + 1) * gray_frame_stride + d.plane_off);
+#pragma unroll
+            for (int k = 0; k < SCAN_VPT; k++) {
+                const int vi = threadIdx.x + k * 256;
+                if (vi < nvec) nxt[k] = gn[vi];
+            }
+        }
         u32 sad = 0;
-        if (st.has_ref)
-            for (int i = threadIdx.x; i < n; i += blockDim.x) sad += (u32)abs((int)g[i] - (int)lref[i]);
+        if (st.has_ref) {
+#pragma unroll
+            for (int k = 0; k < SCAN_VPT; k++) {
+                sad = __builtin_amdgcn_sad_u8(cur[k].x, rv[k].x, sad);
+                sad = __builtin_amdgcn_sad_u8(cur[k].y, rv[k].y, sad);
+                sad = __builtin_amdgcn_sad_u8(cur[k].z, rv[k].z, sad);
+                sad = __builtin_amdgcn_sad_u8(cur[k].w, rv[k].w, sad);
+            }
+        }
         sad = wave_sum_u32(sad);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sad;
+        if ((threadIdx.x & 63) == 0) red[t & 1][threadIdx.x >> 6] = sad;
         __syncthreads();
-        // every thread evaluates the (cheap, uniform) decision chain
-        const u32 tot = red[0] + red[1] + red[2] + red[3];
+        // every lane evaluates the (cheap, uniform) decision chain
+        const u32 tot = red[t & 1][0] + red[t & 1][1] + red[t & 1][2] + red[t & 1][3];
         bool changed = true;
         if (st.has_ref) {
             const double mean_diff = (double)tot / (double)n;
@@ -307,9 +330,9 @@ __global__ __launch_bounds__(256) void k_scan(const SquareDesc* __restrict__ des
             const double presence = (double)__popc(st.hist_bits) / (double)st.hist_len;
             stable = presence >= sp.min_presence;
         }
-        const bool update = should_process && (raw == stable);
-        if (update) {
-            for (int i = threadIdx.x; i < n; i += blockDim.x) lref[i] = g[i];
+        if (should_process && (raw == stable)) {
+#pragma unroll
+            for (int k = 0; k < SCAN_VPT; k++) rv[k] = cur[k];
             st.has_ref = 1;
         }
         if (threadIdx.x == 0) {
@@ -320,21 +343,26 @@ __global__ __launch_bounds__(256) void k_scan(const SquareDesc* __restrict__ des
             if (changed) atomicOr((unsigned long long*)&r->visual_changes, bit);
             if (should_process) atomicOr((unsigned long long*)&r->processed, bit);
         }
-        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SCAN_VPT; k++) cur[k] = nxt[k];
     }
-    if (st.has_ref)
-        for (int i = threadIdx.x; i < n; i += blockDim.x) ref[d.plane_off + i] = lref[i];
+    if (st.has_ref) {
+        uint4* refw = (uint4*)(ref + d.plane_off);
+#pragma unroll
+        for (int k = 0; k < SCAN_VPT; k++) {
+            const int vi = threadIdx.x + k * 256;
+            if (vi < nvec) refw[vi] = rv[k];
+        }
+    }
     if (threadIdx.x == 0) state[sq] = st;
-    (void)flag;
 }
 
 int launch_scan(cbv_ctx* ctx, const SquareDesc* descs, ScanParams sp, const u8* gray, size_t gray_frame_stride,
                 const cbv_sq_stats* stats, u8* ref, ScanState* state, cbv_frame_result* results, int count)
 {
-    size_t lds = CBV_MAX_SQUARE_DIM * CBV_MAX_SQUARE_DIM;
     prof_begin(ctx, CBV_K_SCAN);
-    hipLaunchKernelGGL(k_scan, dim3(sp.n), dim3(256), lds, ctx->stream, descs, sp, gray, gray_frame_stride, stats, ref,
-                       state, results, count);
+    hipLaunchKernelGGL(k_scan, dim3(sp.n), dim3(256), 0, ctx->stream, descs, sp, gray, gray_frame_stride, stats, ref, state,
+                       results, count);
     prof_end(ctx, CBV_K_SCAN);
     CBV_HIP(ctx, hipGetLastError());
     return CBV_OK;

@@ -23,9 +23,9 @@ SHIPPED_PROFILE = {"hue_shift": -86, "sat_scale": 0.91, "val_scale": 2.46, "cont
 # (contrast 1.48, brightness -30, val x2.46) was calibrated for.
 SCENES = {
     "normal": dict(bg_lo=60, bg_span=31, light=(140, 160, 180), dark=(60, 85, 115),
-                   white=(245, 245, 240), black=(20, 20, 25), noise=3, radius=0.36),
+                   white=(245, 245, 240), black=(20, 20, 25), noise=3, radius=0.42),
     "dim": dict(bg_lo=24, bg_span=8, light=(62, 66, 70), dark=(40, 43, 48),
-                white=(84, 84, 82), black=(21, 21, 22), noise=1, radius=0.36),
+                white=(84, 84, 82), black=(21, 21, 22), noise=1, radius=0.42),
 }
 
 
