@@ -110,7 +110,7 @@ def main():
     pipe = BoardPipeline(w, h, F, ctx)
     pipe.configure(pts, profile=profile, grid_lines=grid, chunk=args.chunk)
     pipe.synth(0, F, stream_id=rank, scene="dim")  # inputs resident in HBM before the timed region
-    chunk = pipe._cfg.chunk if pipe._cfg.chunk > 0 else 8
+    chunk = pipe._cfg.chunk if pipe._cfg.chunk > 0 else 32
 
     def barrier():
         torch.cuda.synchronize()

@@ -864,7 +864,7 @@ extern "C" int cbv_pipeline_configure(cbv_pipeline* p, const cbv_pipeline_config
     p->cfg = *cfg;
     p->keep_enhanced = cfg->keep_enhanced != 0;
     int chunk = cfg->chunk;
-    if (chunk <= 0) chunk = 8;
+    if (chunk <= 0) chunk = 32;
     if (chunk > p->max_frames) chunk = p->max_frames;
     p->chunk = chunk;
     if (!host_invert3x3(cfg->M, p->Minv)) memset(p->Minv, 0, sizeof(p->Minv));
