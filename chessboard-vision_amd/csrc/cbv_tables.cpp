@@ -1,7 +1,8 @@
 // Host-side table builders and the small host-only pieces of the path
 // (getPerspectiveTransform's 8x8 LU solve, 3x3 inverse, PieceDetector masks).
 // Compiled with -ffp-contract=off: every float/double operation below rounds
-// once, in the order written.
+// once, in the order written; the only fused operations are explicit fmaf()
+// calls where OpenCV's FMA3-dispatched code uses v_fma.
 #include <float.h>
 #include <limits.h>
 #include <math.h>
@@ -88,8 +89,7 @@ void build_profile_tabs(const cbv_color_profile* p, ProfileTabs* t)
     t->enabled = p->enabled;
     float a = (float)p->contrast, b = (float)p->brightness;
     for (int i = 0; i < 256; i++) {
-        float x = (float)i * a;
-        x = x + b;
+        float x = fmaf((float)i, a, b); // cvtabs_32f: v_fma(src, alpha, beta)
         t->csa[i] = sat8(round_f(fabsf(x)));
         float h = (float)i;
         if (p->radical_mode) {

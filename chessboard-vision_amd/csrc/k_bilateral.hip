@@ -18,8 +18,9 @@
 //     gfx950, like v_sad_u8; only f32 add/mul and simple integer ops are full
 //     rate — tools/ubench_valu.hip);
 //   - the LUT address (sad << 7) | (lane & 31) << 2 is ONE v_alignbit_b32;
-//   - taps are accumulated per output in row-major (dy, dx) order with separate
-//     multiply and add (no FMA contraction): bit-equal to the scalar definition.
+//   - taps are accumulated per output in row-major (dy, dx) order exactly like
+//     OpenCV's FMA3-dispatched body: w = space * colour (mul), sum = fma(px, w, sum),
+//     wsum += w: bit-equal to the oracle.
 #include "cbv_device.h"
 
 #define BL_TW 128        // tile width in pixels (32 strips of 4)
@@ -183,10 +184,10 @@ __global__ __launch_bounds__(BL_THREADS) void k_bilateral(const u8* __restrict__
                         const u32 sad = __builtin_amdgcn_sad_u8(p[j], ctr[a][o], 0u);
                         const u32 addr = __builtin_amdgcn_alignbit(sad, lane_hi, 25);
                         const float wgt = spw * *(const float*)((const u8*)cw + addr);
-                        const float tb = fb[j] * wgt, tg = fg[j] * wgt, tr = fr[j] * wgt;
-                        sb[a][o] = sb[a][o] + tb;
-                        sg[a][o] = sg[a][o] + tg;
-                        sr[a][o] = sr[a][o] + tr;
+                        // v_muladd(v_cvt_f32(b), w, sum_b): fused, like OpenCV's FMA3-dispatched body
+                        sb[a][o] = __fmaf_rn(fb[j], wgt, sb[a][o]);
+                        sg[a][o] = __fmaf_rn(fg[j], wgt, sg[a][o]);
+                        sr[a][o] = __fmaf_rn(fr[j], wgt, sr[a][o]);
                         sw[a][o] = sw[a][o] + wgt;
                     }
                 }

@@ -563,8 +563,7 @@ __global__ void k_norm_lut(const u32* __restrict__ aux, int tiles_total, u8* __r
     double scale = 255.0 * (smax - smin > 2.2204460492503131e-16 ? 1. / (smax - smin) : 0.);
     double shift = 0.0 - smin * scale;
     float a = (float)scale, b = (float)shift;
-    float t = (float)(int)threadIdx.x * a;
-    t = t + b;
+    const float t = __fmaf_rn((float)(int)threadIdx.x, a, b); // cvt_32f: v_fma(src, scale, shift)
     norm_lut[(size_t)blockIdx.x * 256 + threadIdx.x] = d_sat8_f(t);
 }
 

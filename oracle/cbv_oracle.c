@@ -19,8 +19,13 @@
  * this environment to compare with.  HoughCircles (piece_detector.py:232-241)
  * is not restated.
  *
- * Floating point: compiled with -ffp-contract=off; float ops are written in
- * the order of OpenCV's scalar (non-SIMD) code paths, one rounding per op.
+ * Floating point: compiled with -ffp-contract=off, so nothing is fused unless
+ * written as fmaf().  Float ops follow OpenCV 4.x's code paths one rounding
+ * per operation; where the AVX2/FMA3-dispatched SIMD body of OpenCV (the one
+ * an opencv-python wheel runs on any x86-64 CPU since Haswell) uses a fused
+ * multiply-add (v_fma / v_muladd: convertScaleAbs, convertTo inside
+ * normalize, the bilateral accumulation), fmaf() is used here too.  The SSE
+ * baseline path of the same functions differs by at most 1 LSB on rare pixels.
  *
  * Each function cites the reference file:line whose cv2/numpy call it
  * restates.
@@ -63,8 +68,8 @@ static inline int reflect101(int p, int len)
 
 /* ------------------------------------------------------------------ */
 /* A1  cv2.convertScaleAbs  (frame_enhancer.py:71)                     */
-/* dst = saturate_u8(round(|float(src)*alpha + beta|)), alpha/beta as  */
-/* float32 (cvtabs_32f scalar tail).                                   */
+/* dst = saturate_u8(round(|fma(float(src), alpha, beta)|)), alpha/beta */
+/* as float32 (cvtabs_32f: v_fma in the SIMD body).                    */
 /* ------------------------------------------------------------------ */
 ORC_API void orc_convert_scale_abs(const u8* src, int w, int h, int sstride, int cn,
                                    double alpha, double beta, u8* dst, int dstride)
@@ -74,8 +79,7 @@ ORC_API void orc_convert_scale_abs(const u8* src, int w, int h, int sstride, int
         const u8* s = src + (size_t)y * sstride;
         u8* d = dst + (size_t)y * dstride;
         for (int x = 0; x < w * cn; x++) {
-            float t = (float)s[x] * a;
-            t = t + b;
+            float t = fmaf((float)s[x], a, b);
             d[x] = sat_u8_f(fabsf(t));
         }
     }
@@ -246,8 +250,7 @@ ORC_API void orc_apply_color_profile(const u8* src, int w, int h, int sstride, c
         for (int x = 0; x < w; x++) {
             u8 c[3], hsv[3];
             for (int k = 0; k < 3; k++) {
-                float t = (float)s[3 * x + k] * a;
-                t = t + bta;
+                float t = fmaf((float)s[3 * x + k], a, bta);
                 c[k] = sat_u8_f(fabsf(t));
             }
             bgr2hsv_px(c[0], c[1], c[2], hsv);
@@ -557,10 +560,10 @@ ORC_API void orc_bilateral(const u8* src, int w, int h, int sstride, int d, doub
                 const u8* q = sp + ((ptrdiff_t)ody[k] * pw + x + odx[k]) * 3;
                 int b = q[0], g = q[1], r = q[2];
                 float wgt = space_w[k] * color_w[abs(b - b0) + abs(g - g0) + abs(r - r0)];
-                float tb = (float)b * wgt, tg = (float)g * wgt, tr = (float)r * wgt;
-                sb = sb + tb;
-                sg = sg + tg;
-                sr = sr + tr;
+                /* v_muladd(v_cvt_f32(b), w, sum_b) in the dispatched SIMD body */
+                sb = fmaf((float)b, wgt, sb);
+                sg = fmaf((float)g, wgt, sg);
+                sr = fmaf((float)r, wgt, sr);
                 ws = ws + wgt;
             }
             ws = 1.f / ws;
@@ -628,8 +631,7 @@ ORC_API void orc_normalize_lut(int smin_i, int smax_i, u8* lut256)
     double shift = dmin - smin * scale;
     float a = (float)scale, b = (float)shift;
     for (int i = 0; i < 256; i++) {
-        float t = (float)i * a;
-        t = t + b;
+        float t = fmaf((float)i, a, b); /* cvt_32f: v_fma(src, scale, shift) */
         lut256[i] = sat_u8_f(t);
     }
 }

@@ -36,7 +36,9 @@ def test_convert_scale_abs_folds_negative():
     x = np.arange(256, dtype=np.uint8).reshape(1, 256)
     y = O.convert_scale_abs(x, 1.48, -30)
     a, b = np.float32(1.48), np.float32(-30)
-    exp = np.clip(np.rint(np.abs(x.astype(np.float32) * a + b)), 0, 255).astype(np.uint8)
+    # fused multiply-add (v_fma in cvtabs_32f): exact product + addend in float64, ONE rounding to float32
+    fma = (x.astype(np.float64) * np.float64(a) + np.float64(b)).astype(np.float32)
+    exp = np.clip(np.rint(np.abs(fma)), 0, 255).astype(np.uint8)
     assert np.array_equal(y, exp)
     assert y[0, 0] == 30 and y[0, 255] == 255
 
@@ -86,7 +88,8 @@ def test_normalize_stretches_to_full_range():
     mn, mx = int(img.min()), int(img.max())
     scale = 255.0 * (1.0 / (mx - mn))
     a, b = np.float32(scale), np.float32(0.0 - mn * scale)
-    exp = np.clip(np.rint(img.astype(np.float32) * a + b), 0, 255).astype(np.uint8)
+    fma = (img.astype(np.float64) * np.float64(a) + np.float64(b)).astype(np.float32)  # v_fma in cvt_32f
+    exp = np.clip(np.rint(fma), 0, 255).astype(np.uint8)
     assert np.array_equal(out, exp)
 
 
