@@ -542,12 +542,144 @@ __global__ __launch_bounds__(256) void k_sharpen(const u8* __restrict__ src, u8*
     }
 }
 
+// ---------------------------------------------------------------------------
+// Fast path for kernels  a * (3x3 box) + (c - a) * centre  with small integer a, c (the
+// reference's [[-1,-1,-1],[-1,9,-1],[-1,-1,-1]] is a = -1, c = 9).  All sums are exact integers in
+// f32, so the box sum is separated: per staged row 2 adds per byte (reused by three output rows),
+// per output byte 2 adds + 1 mul + 1 fma + min/max + ONE v_cvt_pk_u8_f32 (convert, saturate, pack).
+// The filter is byte-wise with +-3-byte neighbours, so tiles are cut in BYTES (1 KiB x 16 rows,
+// 16-byte lanes, uint4 loads and stores), not in pixels.  f32 add/fma are the full-rate VALU ops on
+// gfx950 (tools/ubench_valu.hip), hence floats rather than packed integer arithmetic.
+// ---------------------------------------------------------------------------
+#define SHB_TB 1024                 // tile width in bytes
+#define SHB_TH 16                   // tile height in rows
+#define SHB_PITCH (SHB_TB + 32)     // LDS row: 16 B halo | 1024 B | 16 B halo
+
+__global__ __launch_bounds__(256) void k_sharpen_box(const u8* __restrict__ src, u8* __restrict__ dst,
+                                                      u32* __restrict__ aux, int tiles_total, Geom g, float a, float ca,
+                                                      int tiles_xn, int tiles_n)
+{
+    __shared__ __attribute__((aligned(16))) u8 tile[(SHB_TH + 2) * SHB_PITCH];
+    __shared__ int red[8];
+    const int tid = xcd_remap(blockIdx.x, tiles_n);
+    const int tyi = tid / tiles_xn, txi = tid - tyi * tiles_xn;
+    const int xb0 = txi * SHB_TB, y0 = tyi * SHB_TH;
+    const size_t fo = (size_t)blockIdx.z * g.frame_stride;
+    const u8* sf = src + fo;
+    u8* df = dst + fo;
+    const int wb = g.w * 3;
+    const bool al16 = (g.stride & 15) == 0;
+    // stage rows y0-1 .. y0+16, bytes [xb0-16, xb0+1040) as 66 uint4 per row
+    for (int i = threadIdx.x; i < (SHB_TH + 2) * (SHB_PITCH / 16); i += blockDim.x) {
+        const int r = i / (SHB_PITCH / 16), c = i - r * (SHB_PITCH / 16);
+        const int sy = d_reflect101(y0 - 1 + r, g.h);
+        const int bs = xb0 - 16 + c * 16;
+        uint4 v;
+        if (al16 && bs >= 0 && bs + 16 <= wb) {
+            v = *(const uint4*)(sf + (size_t)sy * g.stride + bs);
+        } else {
+            u32 w4[4] = {0, 0, 0, 0};
+            if (bs + 16 > -3 && bs < wb + 3) { // only bytes within one pixel of the row are ever used
+                for (int k = 0; k < 16; k++) {
+                    const int bx = bs + k;
+                    // byte bx belongs to pixel floor(bx / 3); reflect the pixel (REFLECT_101), keep the channel
+                    const int pxl = bx >= 0 ? bx / 3 : -((2 - bx) / 3);
+                    const int ch = bx - pxl * 3;
+                    if (pxl >= -1 && pxl <= g.w) w4[k >> 2] |= (u32)sf[(size_t)sy * g.stride + d_reflect101(pxl, g.w) * 3 + ch] << ((k & 3) * 8);
+                }
+            }
+            v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+        }
+        *(uint4*)&tile[r * SHB_PITCH + c * 16] = v;
+    }
+    __syncthreads();
+
+    const int lc = threadIdx.x & 63, rq = threadIdx.x >> 6; // 64 chunks of 16 B x 4 row quads
+    const int x0 = xb0 + lc * 16;
+    float vmin = 3.0e38f, vmax = -3.0e38f;
+    if (x0 < wb) {
+        const int nbytes = min(16, wb - x0);
+        float h[3][16]; // horizontal 3-sums of the last three staged rows
+        float c[2][16]; // centre values of the last two staged rows
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            const int ly = rq * 4 + r; // staged row index (tile row 0 = y0 - 1)
+            const u8* tr = &tile[ly * SHB_PITCH + 16 + lc * 16];
+            u32 d[6];
+            d[0] = *(const u32*)(tr - 4);
+            const uint4 m = *(const uint4*)tr;
+            d[1] = m.x;
+            d[2] = m.y;
+            d[3] = m.z;
+            d[4] = m.w;
+            d[5] = *(const u32*)(tr + 16);
+            float f[22]; // window bytes x0-3 .. x0+18
+#pragma unroll
+            for (int k = 0; k < 22; k++) f[k] = (float)((d[(k + 1) >> 2] >> (((k + 1) & 3) * 8)) & 255u);
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                h[r % 3][k] = (f[k] + f[k + 3]) + f[k + 6];
+                c[r & 1][k] = f[k + 3];
+            }
+            if (r >= 2) {
+                const int yo = y0 + ly - 2; // centre row of the three last staged rows
+                if (yo < g.h) {
+                    u32 o[4] = {0, 0, 0, 0};
+#pragma unroll
+                    for (int k = 0; k < 16; k++) {
+                        const float S = (h[0][k] + h[1][k]) + h[2][k];
+                        const float v = __fmaf_rn(ca, c[(r - 1) & 1][k], a * S);
+                        if (k < nbytes) {
+                            vmin = fminf(vmin, v);
+                            vmax = fmaxf(vmax, v);
+                        }
+                        o[k >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(v, k & 3, o[k >> 2]);
+                    }
+                    u8* q = df + (size_t)yo * g.stride + x0;
+                    if (nbytes == 16 && al16) *(uint4*)q = make_uint4(o[0], o[1], o[2], o[3]);
+                    else
+                        for (int k = 0; k < nbytes; k++) q[k] = (u8)(o[k >> 2] >> ((k & 3) * 8));
+                }
+            }
+        }
+    }
+    int mn = (int)fminf(fmaxf(vmin, 0.f), 255.f), mx = (int)fminf(fmaxf(vmax, 0.f), 255.f);
+    if (vmin > vmax) { // lane produced nothing
+        mn = 255;
+        mx = 0;
+    }
+    mn = wave_min_i32(mn);
+    mx = wave_max_i32(mx);
+    if ((threadIdx.x & 63) == 0) {
+        red[rq] = mn;
+        red[4 + rq] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32* mm = aux + (size_t)blockIdx.z * aux_words(tiles_total) + (size_t)tiles_total * 256;
+        atomicMin(&mm[0], (u32)min(min(red[0], red[1]), min(red[2], red[3])));
+        atomicMax(&mm[1], (u32)max(max(red[4], red[5]), max(red[6], red[7])));
+    }
+}
+
 int launch_sharpen(cbv_ctx* ctx, const u8* src, u8* dst, u32* aux, int tiles, Geom g, const float* k, int batch)
 {
-    int txn = (g.w + SH_TW - 1) / SH_TW, tyn = (g.h + SH_TH - 1) / SH_TH;
+    // a * box + (c - a) * centre with small integers?
+    const float a = k[0], c = k[4];
+    bool box = true;
+    for (int i = 0; i < 9; i++)
+        if (i != 4 && k[i] != a) box = false;
+    if (a != (float)(int)a || c != (float)(int)c || fabsf(a) > 64.f || fabsf(c) > 64.f) box = false;
     prof_begin(ctx, CBV_K_SHARPEN);
-    hipLaunchKernelGGL(k_sharpen, dim3(txn * tyn, 1, batch), dim3(256), 0, ctx->stream, src, dst, aux, tiles, g, k[0],
-                       k[1], k[2], k[3], k[4], k[5], k[6], k[7], k[8], txn, txn * tyn);
+    if (box) {
+        const int txn = (g.w * 3 + SHB_TB - 1) / SHB_TB, tyn = (g.h + SHB_TH - 1) / SHB_TH;
+        hipLaunchKernelGGL(k_sharpen_box, dim3(txn * tyn, 1, batch), dim3(256), 0, ctx->stream, src, dst, aux, tiles, g, a, c - a,
+                           txn, txn * tyn);
+    } else {
+        int txn = (g.w + SH_TW - 1) / SH_TW, tyn = (g.h + SH_TH - 1) / SH_TH;
+        hipLaunchKernelGGL(k_sharpen, dim3(txn * tyn, 1, batch), dim3(256), 0, ctx->stream, src, dst, aux, tiles, g, k[0],
+                           k[1], k[2], k[3], k[4], k[5], k[6], k[7], k[8], txn, txn * tyn);
+    }
     prof_end(ctx, CBV_K_SHARPEN);
     CBV_HIP(ctx, hipGetLastError());
     return CBV_OK;
