@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--lanes", type=int, default=0, help="HIP streams per GPU the chunks are spread over (0 = library default)")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-profile-pass", action="store_true")
     args = ap.parse_args()
@@ -108,7 +109,7 @@ def main():
     profile = S.SHIPPED_PROFILE
 
     pipe = BoardPipeline(w, h, F, ctx)
-    pipe.configure(pts, profile=profile, grid_lines=grid, chunk=args.chunk)
+    pipe.configure(pts, profile=profile, grid_lines=grid, chunk=args.chunk, lanes=args.lanes)
     pipe.synth(0, F, stream_id=rank, scene="dim")  # inputs resident in HBM before the timed region
     chunk = pipe._cfg.chunk if pipe._cfg.chunk > 0 else 32
 

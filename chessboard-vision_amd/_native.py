@@ -82,7 +82,7 @@ class PipelineConfig(C.Structure):
     _fields_ = [("enhance", EnhanceParams), ("M", C.c_double * 9), ("board_size", C.c_int32), ("rot180", C.c_int32),
                 ("n_rois", C.c_int32), ("rois", Roi * MAX_SQUARES), ("history_size", C.c_int32),
                 ("min_presence", C.c_double), ("change_threshold", C.c_double), ("chunk", C.c_int32),
-                ("keep_enhanced", C.c_int32)]
+                ("lanes", C.c_int32), ("keep_enhanced", C.c_int32)]
 
 
 class FrameResult(C.Structure):

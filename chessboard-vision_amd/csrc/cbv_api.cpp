@@ -805,11 +805,20 @@ struct cbv_pipeline {
     int chunk = 8;
     double Minv[9];
     u8* frames = nullptr;
-    u8 *A = nullptr, *B = nullptr;
+    // Lanes: chunk c runs on lane c % n_lanes, each lane with its own HIP stream and scratch, so a
+    // VALU-bound bilateral launch of one chunk overlaps the memory-latency-bound kernels of another.
+    enum { MAX_LANES = 4 };
+    int n_lanes = 1;
+    hipStream_t lane_stream[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t lane_done[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t start_ev = nullptr;
+    u8* A[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+    u8* B[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+    DevBuf lane_small[MAX_LANES];
     u8* enhanced = nullptr; // [max_frames] when keep_enhanced
     u8* warped = nullptr;   // [max_frames][S][S][3]
     size_t warped_stride = 0;
-    DevBuf small, d_descs, d_masks, d_gray, d_stats, d_ref, d_state, d_results, d_coef, d_synth;
+    DevBuf d_descs, d_masks, d_gray, d_stats, d_ref, d_state, d_results, d_coef, d_synth;
     std::vector<SquareDesc> descs;
     size_t plane_total = 0;
     bool keep_enhanced = false;
@@ -839,12 +848,19 @@ extern "C" void cbv_pipeline_destroy(cbv_pipeline* p)
     if (!p) return;
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
+    for (int l = 0; l < cbv_pipeline::MAX_LANES; l++) {
+        if (p->lane_stream[l]) (void)hipStreamSynchronize(p->lane_stream[l]);
+        if (p->A[l]) (void)hipFree(p->A[l]);
+        if (p->B[l]) (void)hipFree(p->B[l]);
+        dev_free(&p->lane_small[l]);
+        if (p->lane_done[l]) (void)hipEventDestroy(p->lane_done[l]);
+        if (p->lane_stream[l]) (void)hipStreamDestroy(p->lane_stream[l]);
+    }
+    if (p->start_ev) (void)hipEventDestroy(p->start_ev);
     if (p->frames) (void)hipFree(p->frames);
-    if (p->A) (void)hipFree(p->A);
-    if (p->B) (void)hipFree(p->B);
     if (p->enhanced) (void)hipFree(p->enhanced);
     if (p->warped) (void)hipFree(p->warped);
-    DevBuf* bufs[] = {&p->small, &p->d_descs, &p->d_masks, &p->d_gray, &p->d_stats, &p->d_ref, &p->d_state, &p->d_results, &p->d_coef, &p->d_synth};
+    DevBuf* bufs[] = {&p->d_descs, &p->d_masks, &p->d_gray, &p->d_stats, &p->d_ref, &p->d_state, &p->d_results, &p->d_coef, &p->d_synth};
     for (auto b : bufs) dev_free(b);
     delete p;
 }
@@ -871,17 +887,29 @@ extern "C" int cbv_pipeline_configure(cbv_pipeline* p, const cbv_pipeline_config
     const int S = cfg->board_size;
     p->warped_stride = ((size_t)S * S * 3 + 255) & ~(size_t)255;
     // (re)allocate
-    if (p->A) (void)hipFree(p->A);
-    if (p->B) (void)hipFree(p->B);
+    int lanes = cfg->lanes <= 0 ? 2 : cfg->lanes;
+    if (lanes > cbv_pipeline::MAX_LANES) lanes = cbv_pipeline::MAX_LANES;
+    if ((p->max_frames + chunk - 1) / chunk < lanes) lanes = (p->max_frames + chunk - 1) / chunk;
+    p->n_lanes = lanes;
+    for (int l = 0; l < cbv_pipeline::MAX_LANES; l++) {
+        if (p->A[l]) (void)hipFree(p->A[l]);
+        if (p->B[l]) (void)hipFree(p->B[l]);
+        p->A[l] = p->B[l] = nullptr;
+    }
     if (p->warped) (void)hipFree(p->warped);
     if (p->enhanced) (void)hipFree(p->enhanced);
-    p->A = p->B = p->warped = p->enhanced = nullptr;
-    CBV_HIP(ctx, hipMalloc((void**)&p->A, p->g.frame_stride * chunk));
-    CBV_HIP(ctx, hipMalloc((void**)&p->B, p->g.frame_stride * chunk));
+    p->warped = p->enhanced = nullptr;
+    if (!p->start_ev) CBV_HIP(ctx, hipEventCreateWithFlags(&p->start_ev, hipEventDisableTiming));
+    for (int l = 0; l < lanes; l++) {
+        CBV_HIP(ctx, hipMalloc((void**)&p->A[l], p->g.frame_stride * chunk));
+        CBV_HIP(ctx, hipMalloc((void**)&p->B[l], p->g.frame_stride * chunk));
+        SmallLayout SL;
+        RC(small_layout(ctx, &p->lane_small[l], cfg->enhance.tiles_x * cfg->enhance.tiles_y, chunk, &SL));
+        if (l > 0 && !p->lane_stream[l]) CBV_HIP(ctx, hipStreamCreateWithFlags(&p->lane_stream[l], hipStreamNonBlocking));
+        if (!p->lane_done[l]) CBV_HIP(ctx, hipEventCreateWithFlags(&p->lane_done[l], hipEventDisableTiming));
+    }
     CBV_HIP(ctx, hipMalloc((void**)&p->warped, p->warped_stride * p->max_frames));
     if (p->keep_enhanced) CBV_HIP(ctx, hipMalloc((void**)&p->enhanced, p->g.frame_stride * p->max_frames));
-    SmallLayout SL;
-    RC(small_layout(ctx, &p->small, cfg->enhance.tiles_x * cfg->enhance.tiles_y, chunk, &SL));
     // squares
     const int n = cfg->n_rois;
     p->descs.assign(n, SquareDesc());
@@ -974,29 +1002,47 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
     CBV_HIP(ctx, hipSetDevice(ctx->device));
     const cbv_pipeline_config& cfg = p->cfg;
     const int S = cfg.board_size, n = cfg.n_rois;
-    SmallLayout SL;
-    RC(small_layout(ctx, &p->small, cfg.enhance.tiles_x * cfg.enhance.tiles_y, p->chunk, &SL));
-    Geom wg; // geometry of the warped board images
-    wg.w = S;
-    wg.h = S;
-    wg.stride = S * 3;
-    wg.frame_stride = p->warped_stride;
-    for (int s0 = slot0; s0 < slot0 + count; s0 += p->chunk) {
+    // Lane 0 is the context's stream; lanes 1.. are worker streams forked from it and joined before
+    // the temporal scan (which needs every frame's statistics, in order).
+    hipStream_t main_stream = ctx->stream;
+    if (p->n_lanes > 1) {
+        CBV_HIP(ctx, hipEventRecord(p->start_ev, main_stream));
+        for (int l = 1; l < p->n_lanes; l++) CBV_HIP(ctx, hipStreamWaitEvent(p->lane_stream[l], p->start_ev, 0));
+    }
+    int ci = 0, rc_all = CBV_OK;
+    for (int s0 = slot0; s0 < slot0 + count && rc_all == CBV_OK; s0 += p->chunk, ci++) {
+        const int lane = ci % p->n_lanes;
+        ctx->stream = lane == 0 ? main_stream : p->lane_stream[lane];
+        SmallLayout SL;
+        rc_all = small_layout(ctx, &p->lane_small[lane], cfg.enhance.tiles_x * cfg.enhance.tiles_y, p->chunk, &SL);
+        if (rc_all) break;
         const int b = std::min(p->chunk, slot0 + count - s0);
         const u8* src = p->frames + p->g.frame_stride * s0;
         u8* res = nullptr;
-        RC(enhance_dev(ctx, src, p->A, p->B, p->g, &cfg.enhance, SL, b, !p->keep_enhanced, &res));
+        rc_all = enhance_dev(ctx, src, p->A[lane], p->B[lane], p->g, &cfg.enhance, SL, b, !p->keep_enhanced, &res);
+        if (rc_all) break;
         u8* wdst = p->warped + p->warped_stride * s0;
         if (p->keep_enhanced) {
-            CBV_HIP(ctx, hipMemcpyAsync(p->enhanced + p->g.frame_stride * s0, res, p->g.frame_stride * b, hipMemcpyDeviceToDevice, ctx->stream));
-            RC(launch_warp(ctx, res, p->g, p->Minv, S, S, cfg.rot180, wdst, S * 3, p->warped_stride, nullptr, b));
+            if (hipMemcpyAsync(p->enhanced + p->g.frame_stride * s0, res, p->g.frame_stride * b, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
+                rc_all = cbv_fail(ctx, CBV_ERR_HIP, "copy of the enhanced frames failed");
+                break;
+            }
+            rc_all = launch_warp(ctx, res, p->g, p->Minv, S, S, cfg.rot180, wdst, S * 3, p->warped_stride, nullptr, b);
         } else {
-            RC(launch_warp(ctx, res, p->g, p->Minv, S, S, cfg.rot180, wdst, S * 3, p->warped_stride, SL.norm_lut, b));
+            rc_all = launch_warp(ctx, res, p->g, p->Minv, S, S, cfg.rot180, wdst, S * 3, p->warped_stride, SL.norm_lut, b);
         }
-        RC(launch_squares_preprocess(ctx, wdst, p->warped_stride, (const SquareDesc*)p->d_descs.p, n, (const int*)p->d_coef.p, 5,
-                                     (u8*)p->d_gray.p + p->plane_total * s0, p->plane_total, b));
-        RC(launch_squares_stats(ctx, (const SquareDesc*)p->d_descs.p, n, (const u8*)p->d_gray.p + p->plane_total * s0, p->plane_total, nullptr,
-                                nullptr, nullptr, (const u8*)p->d_masks.p, 0.f, (cbv_sq_stats*)p->d_stats.p + (size_t)n * s0, b));
+        if (rc_all) break;
+        rc_all = launch_squares_preprocess(ctx, wdst, p->warped_stride, (const SquareDesc*)p->d_descs.p, n, (const int*)p->d_coef.p, 5,
+                                           (u8*)p->d_gray.p + p->plane_total * s0, p->plane_total, b);
+        if (rc_all) break;
+        rc_all = launch_squares_stats(ctx, (const SquareDesc*)p->d_descs.p, n, (const u8*)p->d_gray.p + p->plane_total * s0, p->plane_total,
+                                      nullptr, nullptr, nullptr, (const u8*)p->d_masks.p, 0.f, (cbv_sq_stats*)p->d_stats.p + (size_t)n * s0, b);
+    }
+    ctx->stream = main_stream;
+    if (rc_all) return rc_all;
+    for (int l = 1; l < p->n_lanes; l++) {
+        CBV_HIP(ctx, hipEventRecord(p->lane_done[l], p->lane_stream[l]));
+        CBV_HIP(ctx, hipStreamWaitEvent(main_stream, p->lane_done[l], 0));
     }
     CBV_HIP(ctx, hipMemsetAsync((cbv_frame_result*)p->d_results.p + slot0, 0, sizeof(cbv_frame_result) * count, ctx->stream));
     ScanParams sp;
@@ -1007,7 +1053,6 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
     RC(launch_scan(ctx, (const SquareDesc*)p->d_descs.p, sp, (const u8*)p->d_gray.p + p->plane_total * slot0, p->plane_total,
                    (const cbv_sq_stats*)p->d_stats.p + (size_t)n * slot0, (u8*)p->d_ref.p, (ScanState*)p->d_state.p,
                    (cbv_frame_result*)p->d_results.p + slot0, count));
-    (void)wg;
     return CBV_OK;
 }
 

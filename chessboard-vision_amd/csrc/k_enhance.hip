@@ -333,78 +333,86 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const u8* __restrict__ lab,
     u8* df = dst + fo;
     const bool aligned = (g.stride & 3) == 0;
     const int groups = (g.w + 3) >> 2;
-    const int nrows = y1 - y0;
     const int shift = LAB_SHIFT + (LAB_BASE_SHIFT - INV_GAMMA_SHIFT);
 
-    for (int it = threadIdx.x; it < groups * nrows; it += blockDim.x) {
-        const int row = it / groups, gi = it - row * groups;
-        const int y = y0 + row, x0 = gi * 4;
+    // a lane keeps its 4-pixel column group and walks the chunk's rows: the x interpolation
+    // parameters (tile pair, xa) are computed once per group instead of once per pixel
+    for (int gi = threadIdx.x; gi < groups; gi += blockDim.x) {
+        const int x0 = gi * 4;
         const int npx = min(4, g.w - x0);
-        const float tyf = (float)y * inv_th - 0.5f;
-        const float ya = tyf - (float)d_floor_f(tyf), ya1 = 1.0f - ya;
-        Px4 px, out;
-        out.d[0] = out.d[1] = out.d[2] = 0;
         const bool fast = aligned && npx == 4;
-        const u8* p = sf + (size_t)y * g.stride + (size_t)x0 * 3;
-        if (fast) {
-            const u32* pw = (const u32*)p;
-            px.d[0] = pw[0];
-            px.d[1] = pw[1];
-            px.d[2] = pw[2];
-        } else {
-            px.d[0] = px.d[1] = px.d[2] = 0;
-#pragma unroll
-            for (int k = 0; k < 12; k++)
-                if (k < npx * 3) px_set(px, k, p[k]);
-        }
+        int o1[4], o2[4];
+        float xa[4], xa1[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            if (k < npx) {
-                const int x = x0 + k;
-                const float txf = (float)x * inv_tw - 0.5f;
-                int tx1 = d_floor_f(txf);
-                const float xa = txf - (float)tx1, xa1 = 1.0f - xa;
-                int tx2 = min(tx1 + 1, cg.tiles_x - 1);
-                tx1 = max(tx1, 0);
-                const int v = px_get(px, 3 * k);
-                float ra = (float)lut1[tx1 * 256 + v] * xa1 + (float)lut1[tx2 * 256 + v] * xa;
-                float rb = (float)lut2[tx1 * 256 + v] * xa1 + (float)lut2[tx2 * 256 + v] * xa;
-                float res = ra * ya1 + rb * ya;
-                const int LL = d_sat8_f(res);
-                // Lab2RGBinteger
-                const int aa = px_get(px, 3 * k + 1), bb = px_get(px, 3 * k + 2);
-                const int yv = lab_yf[LL * 2], ify = lab_yf[LL * 2 + 1];
-                const int adiv = ((5 * aa * 53687 + (1 << 7)) >> 13) - 128 * LAB_BASE / 500;
-                const int bdiv = ((bb * 41943 + (1 << 4)) >> 9) - 128 * LAB_BASE / 200 + 1;
-                const int xv = d_ab_to_xz(ify + adiv), zv = d_ab_to_xz(ify - bdiv);
-                int ro = D_DESCALE(invc[0] * xv + invc[1] * yv + invc[2] * zv, shift);
-                int go = D_DESCALE(invc[3] * xv + invc[4] * yv + invc[5] * zv, shift);
-                int bo = D_DESCALE(invc[6] * xv + invc[7] * yv + invc[8] * zv, shift);
-                ro = min(max(ro, 0), INV_GAMMA_TAB_SIZE - 1);
-                go = min(max(go, 0), INV_GAMMA_TAB_SIZE - 1);
-                bo = min(max(bo, 0), INV_GAMMA_TAB_SIZE - 1);
-                px_set(out, 3 * k, d_sat8(inv_gamma[bo]));
-                px_set(out, 3 * k + 1, d_sat8(inv_gamma[go]));
-                px_set(out, 3 * k + 2, d_sat8(inv_gamma[ro]));
-            }
+            const float txf = (float)(x0 + k) * inv_tw - 0.5f;
+            int tx1 = d_floor_f(txf);
+            xa[k] = txf - (float)tx1;
+            xa1[k] = 1.0f - xa[k];
+            o2[k] = min(tx1 + 1, cg.tiles_x - 1) * 256;
+            o1[k] = max(tx1, 0) * 256;
         }
-        u8* q = df + (size_t)y * g.stride + (size_t)x0 * 3;
-        if (fast) {
-            u32* qw = (u32*)q;
-            qw[0] = out.d[0];
-            qw[1] = out.d[1];
-            qw[2] = out.d[2];
-        } else {
+        for (int y = y0; y < y1; y++) {
+            const float tyf = (float)y * inv_th - 0.5f;
+            const float ya = tyf - (float)d_floor_f(tyf), ya1 = 1.0f - ya;
+            Px4 px, out;
+            out.d[0] = out.d[1] = out.d[2] = 0;
+            const u8* p = sf + (size_t)y * g.stride + (size_t)x0 * 3;
+            if (fast) {
+                const u32* pw = (const u32*)p;
+                px.d[0] = pw[0];
+                px.d[1] = pw[1];
+                px.d[2] = pw[2];
+            } else {
+                px.d[0] = px.d[1] = px.d[2] = 0;
 #pragma unroll
-            for (int k = 0; k < 12; k++)
-                if (k < npx * 3) q[k] = (u8)px_get(out, k);
+                for (int k = 0; k < 12; k++)
+                    if (k < npx * 3) px_set(px, k, p[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (k < npx) {
+                    const int v = px_get(px, 3 * k);
+                    float ra = (float)lut1[o1[k] + v] * xa1[k] + (float)lut1[o2[k] + v] * xa[k];
+                    float rb = (float)lut2[o1[k] + v] * xa1[k] + (float)lut2[o2[k] + v] * xa[k];
+                    float res = ra * ya1 + rb * ya;
+                    const int LL = d_sat8_f(res);
+                    // Lab2RGBinteger
+                    const int aa = px_get(px, 3 * k + 1), bb = px_get(px, 3 * k + 2);
+                    const int yv = lab_yf[LL * 2], ify = lab_yf[LL * 2 + 1];
+                    const int adiv = ((5 * aa * 53687 + (1 << 7)) >> 13) - 128 * LAB_BASE / 500;
+                    const int bdiv = ((bb * 41943 + (1 << 4)) >> 9) - 128 * LAB_BASE / 200 + 1;
+                    const int xv = d_ab_to_xz(ify + adiv), zv = d_ab_to_xz(ify - bdiv);
+                    int ro = D_DESCALE(invc[0] * xv + invc[1] * yv + invc[2] * zv, shift);
+                    int go = D_DESCALE(invc[3] * xv + invc[4] * yv + invc[5] * zv, shift);
+                    int bo = D_DESCALE(invc[6] * xv + invc[7] * yv + invc[8] * zv, shift);
+                    ro = min(max(ro, 0), INV_GAMMA_TAB_SIZE - 1);
+                    go = min(max(go, 0), INV_GAMMA_TAB_SIZE - 1);
+                    bo = min(max(bo, 0), INV_GAMMA_TAB_SIZE - 1);
+                    // table entries are <= 255 by construction: saturate_cast is the identity
+                    px_set(out, 3 * k, inv_gamma[bo]);
+                    px_set(out, 3 * k + 1, inv_gamma[go]);
+                    px_set(out, 3 * k + 2, inv_gamma[ro]);
+                }
+            }
+            u8* q = df + (size_t)y * g.stride + (size_t)x0 * 3;
+            if (fast) {
+                u32* qw = (u32*)q;
+                qw[0] = out.d[0];
+                qw[1] = out.d[1];
+                qw[2] = out.d[2];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 12; k++)
+                    if (k < npx * 3) q[k] = (u8)px_get(out, k);
+            }
         }
     }
 }
 
 int launch_clahe_apply(cbv_ctx* ctx, const u8* lab, const u8* luts, u8* dst, Geom g, ClaheGeom cg, int batch)
 {
-    const int rows_per_wg = 4;
+    const int rows_per_wg = 8;
     int tiles = cg.tiles_x * cg.tiles_y;
     size_t lds = INV_GAMMA_TAB_SIZE * 2 + 1024 + 64 + 2 * (size_t)cg.tiles_x * 256;
     if (lds > 64 * 1024) return cbv_fail(ctx, CBV_ERR_UNSUPPORTED, "clahe: tile grid too wide (%d)", cg.tiles_x);

@@ -51,13 +51,60 @@ __global__ __launch_bounds__(256) void k_squares_preprocess(const u8* __restrict
     }
 }
 
+// The default blur (k = 5: 1-4-6-4-1, 8.8 fixed point 16-64-96-64-16) without per-pixel divisions:
+// lanes walk the square as a 16 x 16 grid, reflected neighbour columns/rows are resolved once per
+// column/row, gray rows are staged as u8 and the horizontal pass as u16 in LDS.
+__global__ __launch_bounds__(256) void k_squares_preprocess5(const u8* __restrict__ src, size_t src_frame_stride,
+                                                              const SquareDesc* __restrict__ descs,
+                                                              u8* __restrict__ gray, size_t gray_frame_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    const SquareDesc d = descs[blockIdx.x];
+    if (d.cn == 0) return;
+    const int w = d.w, h = d.h, n = w * h;
+    u8* g = smem;
+    u16* hb = (u16*)(smem + ((n + 15) & ~15));
+    const u8* s = src + (size_t)blockIdx.z * src_frame_stride + d.src_off;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    if (d.cn == 3) {
+        for (int y = ty; y < h; y += 16) {
+            const u8* row = s + (size_t)y * d.stride;
+            for (int x = tx; x < w; x += 16) g[y * w + x] = (u8)d_gray(row[3 * x], row[3 * x + 1], row[3 * x + 2]);
+        }
+    } else {
+        for (int y = ty; y < h; y += 16)
+            for (int x = tx; x < w; x += 16) g[y * w + x] = s[(size_t)y * d.stride + x];
+    }
+    __syncthreads();
+    for (int x = tx; x < w; x += 16) {
+        const int x0 = d_reflect101(x - 2, w), x1 = d_reflect101(x - 1, w), x3 = d_reflect101(x + 1, w), x4 = d_reflect101(x + 2, w);
+        for (int y = ty; y < h; y += 16) {
+            const u8* r = g + y * w;
+            hb[y * w + x] = (u16)(16 * (r[x0] + r[x4]) + 64 * (r[x1] + r[x3]) + 96 * r[x]);
+        }
+    }
+    __syncthreads();
+    u8* out = gray + (size_t)blockIdx.z * gray_frame_stride + d.plane_off;
+    for (int y = ty; y < h; y += 16) {
+        const int y0 = d_reflect101(y - 2, h) * w, y1 = d_reflect101(y - 1, h) * w, y3 = d_reflect101(y + 1, h) * w, y4 = d_reflect101(y + 2, h) * w;
+        for (int x = tx; x < w; x += 16) {
+            const u32 acc = 16u * (hb[y0 + x] + hb[y4 + x]) + 64u * (hb[y1 + x] + hb[y3 + x]) + 96u * hb[y * w + x];
+            out[y * w + x] = (u8)((acc + (1u << 15)) >> 16);
+        }
+    }
+}
+
 int launch_squares_preprocess(cbv_ctx* ctx, const u8* src, size_t src_frame_stride, const SquareDesc* descs, int n,
                               const int* coef_dev, int blur_k, u8* gray, size_t gray_frame_stride, int batch)
 {
     size_t lds = (size_t)((CBV_MAX_SQUARE_DIM * CBV_MAX_SQUARE_DIM + 15) & ~15) + 2 * CBV_MAX_SQUARE_DIM * CBV_MAX_SQUARE_DIM;
     prof_begin(ctx, CBV_K_SQUARES);
-    hipLaunchKernelGGL(k_squares_preprocess, dim3(n, 1, batch), dim3(256), lds, ctx->stream, src, src_frame_stride,
-                       descs, coef_dev, blur_k, gray, gray_frame_stride);
+    if (blur_k == 5)
+        hipLaunchKernelGGL(k_squares_preprocess5, dim3(n, 1, batch), dim3(256), lds, ctx->stream, src, src_frame_stride, descs,
+                           gray, gray_frame_stride);
+    else
+        hipLaunchKernelGGL(k_squares_preprocess, dim3(n, 1, batch), dim3(256), lds, ctx->stream, src, src_frame_stride,
+                           descs, coef_dev, blur_k, gray, gray_frame_stride);
     prof_end(ctx, CBV_K_SQUARES);
     CBV_HIP(ctx, hipGetLastError());
     return CBV_OK;

@@ -42,7 +42,7 @@ class BoardPipeline:
         except Exception:
             pass
 
-    def configure(self, points, profile=None, grid_lines=None, rot180=False, chunk=0, keep_enhanced=False,
+    def configure(self, points, profile=None, grid_lines=None, rot180=False, chunk=0, lanes=0, keep_enhanced=False,
                   clahe_clip_limit=3.0, tile_grid_size=(8, 8), sharpen_kernel=None, display_size=(1280, 720), margin=100,
                   history_size=5, min_presence=0.6, change_threshold=25):
         cfg = N.PipelineConfig()
@@ -72,7 +72,7 @@ class BoardPipeline:
             cfg.rois[i].x0, cfg.rois[i].y0, cfg.rois[i].w, cfg.rois[i].h = x0, y0, w, h
             self.rois_rc.append((r, c))
         cfg.history_size, cfg.min_presence, cfg.change_threshold = history_size, min_presence, change_threshold
-        cfg.chunk, cfg.keep_enhanced = chunk, 1 if keep_enhanced else 0
+        cfg.chunk, cfg.lanes, cfg.keep_enhanced = chunk, lanes, 1 if keep_enhanced else 0
         self.ctx.check(self.ctx.lib.cbv_pipeline_configure(self.h_, cfg))
         self.board_size = S_
         self.matrix = M

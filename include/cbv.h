@@ -208,6 +208,7 @@ typedef struct {
     double min_presence;         /* 0.6 piece_detector.py:41 */
     double change_threshold;     /* 25  piece_detector.py:50 */
     int32_t chunk;               /* frames per kernel launch (0 = default) */
+    int32_t lanes;               /* HIP streams the chunks are spread over (0 = default 2, max 4) */
     int32_t keep_enhanced;       /* 1: materialise process_pipeline's output per frame (cbv_pipeline_download
                                     which = 1); 0: fold the final normalize into the warp gather */
 } cbv_pipeline_config;
