@@ -64,6 +64,11 @@ void build_static_tabs(StaticTabs* t)
         t->inv[i + 3] = round_d((1 << LAB_SHIFT) * XYZ2RGB[i + 3] * D65[i]);
         t->inv[i + 6] = round_d((1 << LAB_SHIFT) * XYZ2RGB[i + 6] * D65[i]);
     }
+    for (int c = 0; c < 3; c++)
+        for (int v = 0; v < 256; v++) {
+            for (int k = 0; k < 3; k++) t->lab_pre[c][v][k] = (int)t->gamma[v] * t->fwd[k * 3 + c] + (c == 0 ? (1 << (LAB_SHIFT - 1)) : 0);
+            t->lab_pre[c][v][3] = 0;
+        }
 }
 
 static inline float np_mod_f32(float a, float b)
@@ -87,6 +92,7 @@ void build_profile_tabs(const cbv_color_profile* p, ProfileTabs* t)
 {
     memset(t, 0, sizeof(*t));
     t->enabled = p->enabled;
+    t->radical = p->radical_mode ? 1 : 0;
     float a = (float)p->contrast, b = (float)p->brightness;
     for (int i = 0; i < 256; i++) {
         float x = fmaf((float)i, a, b); // cvtabs_32f: v_fma(src, alpha, beta)
@@ -108,6 +114,23 @@ void build_profile_tabs(const cbv_color_profile* p, ProfileTabs* t)
             s = s * (float)p->sat_scale;
             t->smap[m][i] = (u8)(int)clipf(s, 0.f, 255.f);
         }
+    }
+    // HSV2RGB_b (hrange 180) front end per byte: h -> sector, fraction; s, v -> [0,1] floats
+    static const int sector_data[6][3] = {{1, 3, 0}, {1, 0, 2}, {3, 0, 1}, {0, 2, 1}, {0, 1, 3}, {2, 1, 0}};
+    for (int i = 0; i < 256; i++) {
+        float h = (float)t->hmap[i] * (6.0f / 180.0f);
+        h = fmodf(h, 6.f);
+        int sector = (int)floorf(h);
+        h = h - (float)sector;
+        if ((unsigned)sector >= 6u) {
+            sector = 0;
+            h = 0.f;
+        }
+        t->hfr[i] = h;
+        t->hfr1[i] = 1.f - h;
+        t->hsel[i] = (u32)sector_data[sector][0] | ((u32)sector_data[sector][1] << 8) | ((u32)sector_data[sector][2] << 16) | (0x0cu << 24);
+        t->v_f[i] = (float)t->vmap[i] * (1.0f / 255.0f);
+        for (int m = 0; m < 2; m++) t->s_f[m][i] = (float)t->smap[m][i] * (1.0f / 255.0f);
     }
 }
 

@@ -205,9 +205,10 @@ __global__ __launch_bounds__(BL_THREADS) void k_bilateral(const u8* __restrict__
 #pragma unroll
                 for (int o = 0; o < 4; o++) {
                     const float inv = 1.f / sw[a][o];
-                    px_set(out, 3 * o, d_round_f(sb[a][o] * inv));
-                    px_set(out, 3 * o + 1, d_round_f(sg[a][o] * inv));
-                    px_set(out, 3 * o + 2, d_round_f(sr[a][o] * inv));
+                    // v_cvt_pk_u8_f32: cvRound (half to even) + pack; the value is a weighted mean of bytes, already in range
+                    out.d[(3 * o) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(sb[a][o] * inv, (3 * o) & 3, out.d[(3 * o) >> 2]);
+                    out.d[(3 * o + 1) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(sg[a][o] * inv, (3 * o + 1) & 3, out.d[(3 * o + 1) >> 2]);
+                    out.d[(3 * o + 2) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(sr[a][o] * inv, (3 * o + 2) & 3, out.d[(3 * o + 2) >> 2]);
                 }
                 u8* q = dst + (size_t)f * g.frame_stride + (size_t)y * g.stride + (size_t)x * 3;
                 const int npx = min(4, g.w - x);

@@ -38,74 +38,63 @@ int launch_reset_aux(cbv_ctx* ctx, u32* aux, int tiles, int batch)
 struct ColorLds {
     int sdiv[256];
     int hdiv[256];
-    u16 gamma[256];
     u16 cbrt[LAB_CBRT_TAB_SIZE_B];
+    __attribute__((aligned(16))) int lab_pre[3][256][4];
     ProfileTabs pt;
-    int fwd[9];
     u32 hist[256 * 8]; // 8 bank-interleaved copies: hist[bin * 8 + (lane & 7)]
 };
 
-// RGB2HSV_b -> table maps of the numpy section -> HSV2RGB_b (float)
-__device__ __forceinline__ void d_profile_px(const ColorLds& L, int& b, int& g, int& r)
+// v_perm_b32 helpers (byte k of the result = byte sel[k] of {hi, lo}: 0-3 from lo, 4-7 from hi, 0x0c = 0)
+__device__ __forceinline__ u32 d_pack3(int x, int y, int z) // x | y << 8 | z << 16 of three values already in [0,255]
+{
+    const u32 t = __builtin_amdgcn_perm((u32)y, (u32)x, 0x0c0c0400u);
+    return __builtin_amdgcn_perm((u32)z, t, 0x0c040100u);
+}
+
+// apply_color_profile for one pixel: byte maps, integer RGB2HSV_b, float HSV2RGB_b whose per-byte
+// front end (sector, fraction, s/255, v/255) is tabulated.  Returns b | g << 8 | r << 16.
+__device__ __forceinline__ u32 d_profile_px(const ColorLds& L, int b, int g, int r, bool radical)
 {
     b = L.pt.csa[b];
     g = L.pt.csa[g];
     r = L.pt.csa[r];
-    int v = max(b, max(g, r)), vmin = min(b, min(g, r));
-    int diff = v - vmin;
-    int vr = v == r ? -1 : 0, vg = v == g ? -1 : 0;
-    int s = (diff * L.sdiv[v] + (1 << 11)) >> 12;
+    const int v = max(b, max(g, r)), vmin = min(b, min(g, r));
+    const int diff = v - vmin;
+    const int vr = v == r ? -1 : 0, vg = v == g ? -1 : 0;
+    const int s = (diff * L.sdiv[v] + (1 << 11)) >> 12;
     int h = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
     h = (h * L.hdiv[diff] + (1 << 11)) >> 12;
-    h += h < 0 ? 180 : 0;
-    h = d_sat8(h);
-    // numpy float32 section as byte maps
-    int m = L.pt.hmask[h];
-    int hh = L.pt.hmap[h];
-    int ss = L.pt.smap[m][s & 255];
-    int vv = L.pt.vmap[v];
-    // HSV2RGB_b
-    float fh = (float)hh;
-    float fs = (float)ss * (1.0f / 255.0f);
-    float fv = (float)vv * (1.0f / 255.0f);
-    float fb, fg, fr;
-    if (fs == 0.f) {
-        fb = fg = fr = fv;
-    } else {
-        fh = fh * (6.0f / 180.0f);
-        fh = fh >= 6.f ? fh - 6.f : fh; // == fmodf(fh, 6) for fh in [0, 12)
-        int sector = d_floor_f(fh);
-        fh = fh - (float)sector;
-        if ((unsigned)sector >= 6u) {
-            sector = 0;
-            fh = 0.f;
-        }
-        float t0 = fv;
-        float t1 = fv * (1.f - fs);
-        float t2 = fv * (1.f - fs * fh);
-        float t3 = fv * (1.f - fs * (1.f - fh));
-        // sector table {1,3,0},{1,0,2},{3,0,1},{0,2,1},{0,1,3},{2,1,0}
-        fb = sector == 0 ? t1 : sector == 1 ? t1 : sector == 2 ? t3 : sector == 3 ? t0 : sector == 4 ? t0 : t2;
-        fg = sector == 0 ? t3 : sector == 1 ? t0 : sector == 2 ? t0 : sector == 3 ? t2 : sector == 4 ? t1 : t1;
-        fr = sector == 0 ? t0 : sector == 1 ? t2 : sector == 2 ? t1 : sector == 3 ? t1 : sector == 4 ? t3 : t0;
-    }
-    b = d_sat8_f(fb * 255.0f);
-    g = d_sat8_f(fg * 255.0f);
-    r = d_sat8_f(fr * 255.0f);
+    h += h < 0 ? 180 : 0; // 0 <= h <= 180: saturate_cast<uchar> is the identity
+    const int m = radical ? L.pt.hmask[h] : 0;
+    const float fs = L.pt.s_f[m][s & 255];
+    const float fv = L.pt.v_f[v];
+    const float f = L.pt.hfr[h], f1 = L.pt.hfr1[h];
+    // tab = {v, v(1-s), v(1-s f), v(1-s(1-f))}; with s == 0 every entry equals v, as OpenCV's branch returns
+    const float t1 = fv * (1.f - fs);
+    const float t2 = fv * (1.f - fs * f);
+    const float t3 = fv * (1.f - fs * f1);
+    u32 T = __builtin_amdgcn_cvt_pk_u8_f32(fv * 255.0f, 0, 0u); // round-half-even + saturate + pack
+    T = __builtin_amdgcn_cvt_pk_u8_f32(t1 * 255.0f, 1, T);
+    T = __builtin_amdgcn_cvt_pk_u8_f32(t2 * 255.0f, 2, T);
+    T = __builtin_amdgcn_cvt_pk_u8_f32(t3 * 255.0f, 3, T);
+    return __builtin_amdgcn_perm(T, T, L.pt.hsel[h]);
 }
 
-// RGB2Lab_b (integer)
-__device__ __forceinline__ void d_bgr2lab_px(const ColorLds& L, int b, int g, int r, int& oL, int& oa, int& ob)
+// RGB2Lab_b (integer).  Returns L | a << 8 | b << 16; oL receives L.
+__device__ __forceinline__ u32 d_bgr2lab_px(const ColorLds& L, int b, int g, int r, int& oL)
 {
     const int Lscale = (116 * 255 + 50) / 100;
     const int Lshift = -((16 * 255 * (1 << LAB_SHIFT2) + 50) / 100);
-    int R = L.gamma[b], G = L.gamma[g], B = L.gamma[r]; // positional naming as in OpenCV
-    int fX = L.cbrt[D_DESCALE(R * L.fwd[0] + G * L.fwd[1] + B * L.fwd[2], LAB_SHIFT)];
-    int fY = L.cbrt[D_DESCALE(R * L.fwd[3] + G * L.fwd[4] + B * L.fwd[5], LAB_SHIFT)];
-    int fZ = L.cbrt[D_DESCALE(R * L.fwd[6] + G * L.fwd[7] + B * L.fwd[8], LAB_SHIFT)];
+    const int4 cb = *(const int4*)L.lab_pre[0][b];
+    const int4 cg = *(const int4*)L.lab_pre[1][g];
+    const int4 cr = *(const int4*)L.lab_pre[2][r];
+    const int fX = L.cbrt[(cb.x + cg.x + cr.x) >> LAB_SHIFT];
+    const int fY = L.cbrt[(cb.y + cg.y + cr.y) >> LAB_SHIFT];
+    const int fZ = L.cbrt[(cb.z + cg.z + cr.z) >> LAB_SHIFT];
     oL = d_sat8(D_DESCALE(Lscale * fY + Lshift, LAB_SHIFT2));
-    oa = d_sat8(D_DESCALE(500 * (fX - fY) + 128 * (1 << LAB_SHIFT2), LAB_SHIFT2));
-    ob = d_sat8(D_DESCALE(200 * (fY - fZ) + 128 * (1 << LAB_SHIFT2), LAB_SHIFT2));
+    const int oa = d_sat8(D_DESCALE(500 * (fX - fY) + 128 * (1 << LAB_SHIFT2), LAB_SHIFT2));
+    const int ob = d_sat8(D_DESCALE(200 * (fY - fZ) + 128 * (1 << LAB_SHIFT2), LAB_SHIFT2));
+    return d_pack3(oL, oa, ob);
 }
 
 // grid: x = row slices of a tile, y = tile, z = frame.  One wave per row.
@@ -118,10 +107,9 @@ __global__ __launch_bounds__(256) void k_color_lab_hist(const u8* __restrict__ s
     __shared__ ColorLds L;
     lds_copy(L.sdiv, st->sdiv, sizeof(L.sdiv));
     lds_copy(L.hdiv, st->hdiv, sizeof(L.hdiv));
-    lds_copy(L.gamma, st->gamma, sizeof(L.gamma));
     lds_copy(L.cbrt, st->cbrt, sizeof(L.cbrt));
+    lds_copy(L.lab_pre, st->lab_pre, sizeof(L.lab_pre));
     lds_copy(&L.pt, pt, sizeof(ProfileTabs));
-    if (threadIdx.x < 9) L.fwd[threadIdx.x] = st->fwd[threadIdx.x];
     for (int i = threadIdx.x; i < 256 * 8; i += blockDim.x) L.hist[i] = 0;
     __syncthreads();
 
@@ -136,6 +124,8 @@ __global__ __launch_bounds__(256) void k_color_lab_hist(const u8* __restrict__ s
     const int ex0 = tx * cg.tw;
     const bool aligned = ((cg.tw & 3) == 0) && ((g.stride & 3) == 0);
     const int groups = (cg.tw + 3) >> 2;
+    const bool radical = L.pt.radical != 0;
+    const u32 hist_lane = (u32)(lane & 7) << 29; // v_alignbit(L, hist_lane, 27) = (L << 5) | (lane & 7) << 2: byte address of the copy
 
     for (int rr = r0 + wave; rr < r1; rr += 4) {
         const int ey = ty * cg.th + rr;
@@ -144,8 +134,7 @@ __global__ __launch_bounds__(256) void k_color_lab_hist(const u8* __restrict__ s
         for (int gi = lane; gi < groups; gi += 64) {
             const int ex = ex0 + gi * 4;
             const int npx = min(4, cg.tw - gi * 4);
-            Px4 px, out;
-            out.d[0] = out.d[1] = out.d[2] = 0;
+            Px4 px;
             const bool fast = aligned && npx == 4 && ex + 3 < g.w;
             if (fast) {
                 const u32* p = (const u32*)(sf + (size_t)sy * g.stride + (size_t)ex * 3);
@@ -165,38 +154,40 @@ __global__ __launch_bounds__(256) void k_color_lab_hist(const u8* __restrict__ s
                     }
                 }
             }
+            u32 P[4] = {0, 0, 0, 0}; // per pixel: three output bytes in the low 24 bits
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 if (k < npx) {
                     int b = px_get(px, 3 * k), gg = px_get(px, 3 * k + 1), r = px_get(px, 3 * k + 2);
-                    if (do_profile) d_profile_px(L, b, gg, r);
-                    if (do_lab) {
-                        int oL, oa, ob;
-                        d_bgr2lab_px(L, b, gg, r, oL, oa, ob);
-                        atomicAdd(&L.hist[oL * 8 + (lane & 7)], 1u);
-                        b = oL;
-                        gg = oa;
-                        r = ob;
+                    u32 v = (u32)b | ((u32)gg << 8) | ((u32)r << 16);
+                    if (do_profile) {
+                        v = d_profile_px(L, b, gg, r, radical);
+                        b = v & 255;
+                        gg = (v >> 8) & 255;
+                        r = (v >> 16) & 255;
                     }
-                    px_set(out, 3 * k, b);
-                    px_set(out, 3 * k + 1, gg);
-                    px_set(out, 3 * k + 2, r);
+                    if (do_lab) {
+                        int oL;
+                        v = d_bgr2lab_px(L, b, gg, r, oL);
+                        atomicAdd((u32*)((u8*)L.hist + __builtin_amdgcn_alignbit((u32)oL, hist_lane, 27)), 1u);
+                    }
+                    P[k] = v;
                 }
             }
             if (row_in) {
                 if (fast) {
                     u32* q = (u32*)(df + (size_t)ey * g.stride + (size_t)ex * 3);
-                    q[0] = out.d[0];
-                    q[1] = out.d[1];
-                    q[2] = out.d[2];
+                    q[0] = __builtin_amdgcn_perm(P[1], P[0], 0x04020100u);
+                    q[1] = __builtin_amdgcn_perm(P[2], P[1], 0x05040201u);
+                    q[2] = __builtin_amdgcn_perm(P[3], P[2], 0x06050402u);
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         if (k < npx && ex + k < g.w) {
                             u8* q = df + (size_t)ey * g.stride + (size_t)(ex + k) * 3;
-                            q[0] = (u8)px_get(out, 3 * k);
-                            q[1] = (u8)px_get(out, 3 * k + 1);
-                            q[2] = (u8)px_get(out, 3 * k + 2);
+                            q[0] = (u8)(P[k] & 255);
+                            q[1] = (u8)((P[k] >> 8) & 255);
+                            q[2] = (u8)((P[k] >> 16) & 255);
                         }
                     }
                 }
@@ -218,7 +209,12 @@ __global__ __launch_bounds__(256) void k_color_lab_hist(const u8* __restrict__ s
 int launch_color_lab_hist(cbv_ctx* ctx, const u8* src, u8* lab, u32* aux, Geom g, ClaheGeom cg, int batch,
                           int do_profile, int do_lab)
 {
-    const int rows_per_wg = 8;
+    // A workgroup stages ~35 KB of tables, so give it as many rows of its tile as the launch can
+    // afford while still putting >= ~1024 workgroups on the chip.
+    int slices = 1024 / (cg.tiles_x * cg.tiles_y * batch);
+    if (slices < 1) slices = 1;
+    if (slices > (cg.th + 3) / 4) slices = (cg.th + 3) / 4;
+    const int rows_per_wg = (cg.th + slices - 1) / slices;
     dim3 grid((cg.th + rows_per_wg - 1) / rows_per_wg, cg.tiles_x * cg.tiles_y, batch);
     prof_begin(ctx, CBV_K_COLOR_LAB_HIST);
     hipLaunchKernelGGL(k_color_lab_hist, grid, dim3(256), 0, ctx->stream, src, lab, aux, g, cg, ctx->tabs, ctx->ptabs,
@@ -355,8 +351,8 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const u8* __restrict__ lab,
         for (int y = y0; y < y1; y++) {
             const float tyf = (float)y * inv_th - 0.5f;
             const float ya = tyf - (float)d_floor_f(tyf), ya1 = 1.0f - ya;
-            Px4 px, out;
-            out.d[0] = out.d[1] = out.d[2] = 0;
+            Px4 px;
+            u32 P[4] = {0, 0, 0, 0};
             const u8* p = sf + (size_t)y * g.stride + (size_t)x0 * 3;
             if (fast) {
                 const u32* pw = (const u32*)p;
@@ -376,7 +372,7 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const u8* __restrict__ lab,
                     float ra = (float)lut1[o1[k] + v] * xa1[k] + (float)lut1[o2[k] + v] * xa[k];
                     float rb = (float)lut2[o1[k] + v] * xa1[k] + (float)lut2[o2[k] + v] * xa[k];
                     float res = ra * ya1 + rb * ya;
-                    const int LL = d_sat8_f(res);
+                    const int LL = (int)__builtin_amdgcn_cvt_pk_u8_f32(res, 0, 0u); // round-half-even + saturate
                     // Lab2RGBinteger
                     const int aa = px_get(px, 3 * k + 1), bb = px_get(px, 3 * k + 2);
                     const int yv = lab_yf[LL * 2], ify = lab_yf[LL * 2 + 1];
@@ -390,21 +386,23 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const u8* __restrict__ lab,
                     go = min(max(go, 0), INV_GAMMA_TAB_SIZE - 1);
                     bo = min(max(bo, 0), INV_GAMMA_TAB_SIZE - 1);
                     // table entries are <= 255 by construction: saturate_cast is the identity
-                    px_set(out, 3 * k, inv_gamma[bo]);
-                    px_set(out, 3 * k + 1, inv_gamma[go]);
-                    px_set(out, 3 * k + 2, inv_gamma[ro]);
+                    P[k] = d_pack3(inv_gamma[bo], inv_gamma[go], inv_gamma[ro]);
                 }
             }
             u8* q = df + (size_t)y * g.stride + (size_t)x0 * 3;
             if (fast) {
                 u32* qw = (u32*)q;
-                qw[0] = out.d[0];
-                qw[1] = out.d[1];
-                qw[2] = out.d[2];
+                qw[0] = __builtin_amdgcn_perm(P[1], P[0], 0x04020100u);
+                qw[1] = __builtin_amdgcn_perm(P[2], P[1], 0x05040201u);
+                qw[2] = __builtin_amdgcn_perm(P[3], P[2], 0x06050402u);
             } else {
 #pragma unroll
-                for (int k = 0; k < 12; k++)
-                    if (k < npx * 3) q[k] = (u8)px_get(out, k);
+                for (int k = 0; k < 4; k++)
+                    if (k < npx) {
+                        q[3 * k] = (u8)(P[k] & 255);
+                        q[3 * k + 1] = (u8)((P[k] >> 8) & 255);
+                        q[3 * k + 2] = (u8)((P[k] >> 16) & 255);
+                    }
             }
         }
     }
