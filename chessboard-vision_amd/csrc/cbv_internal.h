@@ -31,9 +31,6 @@ struct StaticTabs {
     u16 lab_yf[512];                     // LabToYF_b (y, ify) pairs
     int fwd[9];                          // RGB2Lab_b coefficients (BGR order)
     int inv[9];                          // Lab2RGBinteger coefficients
-    // gamma[v] * fwd[.][c] per source channel c: {X, Y, Z, 0} contributions, the descale rounding
-    // constant folded into channel 0 (one 16-byte LDS read replaces a table read + three multiplies)
-    int lab_pre[3][256][4];
 };
 
 // apply_color_profile reduced to byte->byte tables (frame_enhancer.py:71-97)
@@ -48,7 +45,6 @@ struct ProfileTabs {
     // HSV2RGB_b inputs per byte, evaluated on the host in float32 exactly as the device used to:
     u32 hsel[256];    // v_perm selector of (b, g, r) among {v, v(1-s), v(1-s f), v(1-s(1-f))} for hue byte h
     float hfr[256];   // f  = frac(hmap[h] * 6/180)
-    float hfr1[256];  // 1 - f
     float s_f[2][256]; // smap[m][s] * (1/255)
     float v_f[256];    // vmap[v] * (1/255)
 };

@@ -64,11 +64,6 @@ void build_static_tabs(StaticTabs* t)
         t->inv[i + 3] = round_d((1 << LAB_SHIFT) * XYZ2RGB[i + 3] * D65[i]);
         t->inv[i + 6] = round_d((1 << LAB_SHIFT) * XYZ2RGB[i + 6] * D65[i]);
     }
-    for (int c = 0; c < 3; c++)
-        for (int v = 0; v < 256; v++) {
-            for (int k = 0; k < 3; k++) t->lab_pre[c][v][k] = (int)t->gamma[v] * t->fwd[k * 3 + c] + (c == 0 ? (1 << (LAB_SHIFT - 1)) : 0);
-            t->lab_pre[c][v][3] = 0;
-        }
 }
 
 static inline float np_mod_f32(float a, float b)
@@ -127,7 +122,6 @@ void build_profile_tabs(const cbv_color_profile* p, ProfileTabs* t)
             h = 0.f;
         }
         t->hfr[i] = h;
-        t->hfr1[i] = 1.f - h;
         t->hsel[i] = (u32)sector_data[sector][0] | ((u32)sector_data[sector][1] << 8) | ((u32)sector_data[sector][2] << 16) | (0x0cu << 24);
         t->v_f[i] = (float)t->vmap[i] * (1.0f / 255.0f);
         for (int m = 0; m < 2; m++) t->s_f[m][i] = (float)t->smap[m][i] * (1.0f / 255.0f);

@@ -42,11 +42,12 @@ __global__ __launch_bounds__(BL_THREADS) void k_bilateral(const u8* __restrict__
                                                            const BilateralTabs* __restrict__ bt, int tiles_xn,
                                                            int tiles_yn, int batch)
 {
-    extern __shared__ __attribute__((aligned(16))) u8 smem[];
-    float* cw = (float*)smem;                                   // [768][32]
-    u32* tile = (u32*)(smem + BL_LUT_WORDS * 4);                // [(BL_TH + 2R)][BL_PITCH]
-    float* sw2d = (float*)(tile + (BL_TH + 2 * R) * BL_PITCH);   // [2R+1][9] space weights by (dy, dx)
-    int* reach = (int*)(sw2d + 96);                             // [2R+1] half-width of the disc per row
+    // static LDS (137.9 KB): compile-time addresses let the LUT gather use the ds_read immediate offset
+    // instead of a per-lookup v_add of the dynamic-LDS base
+    __shared__ __attribute__((aligned(16))) float cw[BL_LUT_WORDS];              // [768][32]
+    __shared__ __attribute__((aligned(16))) u32 tile[(BL_TH + 2 * R) * BL_PITCH];
+    __shared__ float sw2d[96];                                                  // [2R+1][9] space weights by (dy, dx)
+    __shared__ int reach[16];                                                   // [2R+1] half-width of the disc per row
     constexpr int ROWS = BL_TH + 2 * R;
     constexpr int GROUPS = BL_PITCH / 4;                        // 4-pixel groups per tile row
     constexpr int NG = ROWS * GROUPS;                           // groups per tile (<= 2448)
@@ -232,17 +233,11 @@ static int launch_bilateral_r(cbv_ctx* ctx, const u8* src, u8* dst, Geom g, int 
 {
     const int txn = (g.w + BL_TW - 1) / BL_TW, tyn = (g.h + BL_TH - 1) / BL_TH;
     const int ntiles = txn * tyn * batch;
-    const size_t lds = (size_t)BL_LUT_WORDS * 4 + (size_t)(BL_TH + 2 * R) * BL_PITCH * 4 + 96 * 4 + 16 * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        CBV_HIP(ctx, hipFuncSetAttribute((const void*)k_bilateral<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
     int grid = ctx->num_cus < ntiles ? ctx->num_cus : ntiles; // one persistent workgroup per CU
     grid = (grid + 7) & ~7;                                   // whole XCD groups
     if (grid > ntiles) grid = ntiles;
     prof_begin(ctx, CBV_K_BILATERAL);
-    hipLaunchKernelGGL(k_bilateral<R>, dim3(grid), dim3(BL_THREADS), lds, ctx->stream, src, dst, g, ctx->btabs, txn, tyn,
+    hipLaunchKernelGGL(k_bilateral<R>, dim3(grid), dim3(BL_THREADS), 0, ctx->stream, src, dst, g, ctx->btabs, txn, tyn,
                        batch);
     prof_end(ctx, CBV_K_BILATERAL);
     CBV_HIP(ctx, hipGetLastError());

@@ -39,7 +39,8 @@ struct ColorLds {
     int sdiv[256];
     int hdiv[256];
     u16 cbrt[LAB_CBRT_TAB_SIZE_B];
-    __attribute__((aligned(16))) int lab_pre[3][256][4];
+    u16 gamma[256];
+    int fwd[9];
     ProfileTabs pt;
     u32 hist[256 * 8]; // 8 bank-interleaved copies: hist[bin * 8 + (lane & 7)]
 };
@@ -68,7 +69,7 @@ __device__ __forceinline__ u32 d_profile_px(const ColorLds& L, int b, int g, int
     const int m = radical ? L.pt.hmask[h] : 0;
     const float fs = L.pt.s_f[m][s & 255];
     const float fv = L.pt.v_f[v];
-    const float f = L.pt.hfr[h], f1 = L.pt.hfr1[h];
+    const float f = L.pt.hfr[h], f1 = 1.f - f;
     // tab = {v, v(1-s), v(1-s f), v(1-s(1-f))}; with s == 0 every entry equals v, as OpenCV's branch returns
     const float t1 = fv * (1.f - fs);
     const float t2 = fv * (1.f - fs * f);
@@ -85,12 +86,13 @@ __device__ __forceinline__ u32 d_bgr2lab_px(const ColorLds& L, int b, int g, int
 {
     const int Lscale = (116 * 255 + 50) / 100;
     const int Lshift = -((16 * 255 * (1 << LAB_SHIFT2) + 50) / 100);
-    const int4 cb = *(const int4*)L.lab_pre[0][b];
-    const int4 cg = *(const int4*)L.lab_pre[1][g];
-    const int4 cr = *(const int4*)L.lab_pre[2][r];
-    const int fX = L.cbrt[(cb.x + cg.x + cr.x) >> LAB_SHIFT];
-    const int fY = L.cbrt[(cb.y + cg.y + cr.y) >> LAB_SHIFT];
-    const int fZ = L.cbrt[(cb.z + cg.z + cr.z) >> LAB_SHIFT];
+    // LDS gathers are the scarce resource of this kernel (32 lanes/clk/CU, bank conflicts on
+    // data-dependent addresses): three 16-bit gamma reads + nine 24-bit multiplies beat three
+    // 16-byte reads of premultiplied rows.
+    const int R = L.gamma[b], G = L.gamma[g], B = L.gamma[r]; // positional naming as in OpenCV
+    const int fX = L.cbrt[(__mul24(R, L.fwd[0]) + __mul24(G, L.fwd[1]) + __mul24(B, L.fwd[2]) + (1 << (LAB_SHIFT - 1))) >> LAB_SHIFT];
+    const int fY = L.cbrt[(__mul24(R, L.fwd[3]) + __mul24(G, L.fwd[4]) + __mul24(B, L.fwd[5]) + (1 << (LAB_SHIFT - 1))) >> LAB_SHIFT];
+    const int fZ = L.cbrt[(__mul24(R, L.fwd[6]) + __mul24(G, L.fwd[7]) + __mul24(B, L.fwd[8]) + (1 << (LAB_SHIFT - 1))) >> LAB_SHIFT];
     oL = d_sat8(D_DESCALE(Lscale * fY + Lshift, LAB_SHIFT2));
     const int oa = d_sat8(D_DESCALE(500 * (fX - fY) + 128 * (1 << LAB_SHIFT2), LAB_SHIFT2));
     const int ob = d_sat8(D_DESCALE(200 * (fY - fZ) + 128 * (1 << LAB_SHIFT2), LAB_SHIFT2));
@@ -108,7 +110,8 @@ __global__ __launch_bounds__(256) void k_color_lab_hist(const u8* __restrict__ s
     lds_copy(L.sdiv, st->sdiv, sizeof(L.sdiv));
     lds_copy(L.hdiv, st->hdiv, sizeof(L.hdiv));
     lds_copy(L.cbrt, st->cbrt, sizeof(L.cbrt));
-    lds_copy(L.lab_pre, st->lab_pre, sizeof(L.lab_pre));
+    lds_copy(L.gamma, st->gamma, sizeof(L.gamma));
+    if (threadIdx.x < 9) L.fwd[threadIdx.x] = st->fwd[threadIdx.x];
     lds_copy(&L.pt, pt, sizeof(ProfileTabs));
     for (int i = threadIdx.x; i < 256 * 8; i += blockDim.x) L.hist[i] = 0;
     __syncthreads();
