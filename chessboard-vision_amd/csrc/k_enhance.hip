@@ -287,17 +287,18 @@ __device__ __forceinline__ int d_ab_to_xz(int i)
     return i * i / LAB_BASE * i / LAB_BASE;
 }
 
+#define CLAHE_MAX_TILES_X 32
 __global__ __launch_bounds__(256) void k_clahe_apply(const u8* __restrict__ lab, const u8* __restrict__ luts,
                                                       u8* __restrict__ dst, Geom g, ClaheGeom cg,
                                                       const StaticTabs* __restrict__ st, int rows_per_wg,
                                                       int tiles_total)
 {
-    extern __shared__ __attribute__((aligned(16))) u8 smem[];
-    u16* inv_gamma = (u16*)smem;                               // 8192 B
-    u16* lab_yf = (u16*)(smem + INV_GAMMA_TAB_SIZE * 2);       // 1024 B
-    int* invc = (int*)(smem + INV_GAMMA_TAB_SIZE * 2 + 1024);  // 64 B (9 used)
-    u8* lut1 = smem + INV_GAMMA_TAB_SIZE * 2 + 1024 + 64;      // tiles_x * 256
-    u8* lut2 = lut1 + cg.tiles_x * 256;
+    // static LDS: table addresses become ds_read immediates (no per-lookup base add)
+    __shared__ u16 inv_gamma[INV_GAMMA_TAB_SIZE];
+    __shared__ u16 lab_yf[512];
+    __shared__ int invc[16];
+    __shared__ u8 lut1[CLAHE_MAX_TILES_X * 256];
+    __shared__ u8 lut2[CLAHE_MAX_TILES_X * 256];
 
     // band b holds the rows whose unclamped ty1 is b - 1
     const int band = blockIdx.y;
@@ -382,9 +383,10 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const u8* __restrict__ lab,
                     const int adiv = ((5 * aa * 53687 + (1 << 7)) >> 13) - 128 * LAB_BASE / 500;
                     const int bdiv = ((bb * 41943 + (1 << 4)) >> 9) - 128 * LAB_BASE / 200 + 1;
                     const int xv = d_ab_to_xz(ify + adiv), zv = d_ab_to_xz(ify - bdiv);
-                    int ro = D_DESCALE(invc[0] * xv + invc[1] * yv + invc[2] * zv, shift);
-                    int go = D_DESCALE(invc[3] * xv + invc[4] * yv + invc[5] * zv, shift);
-                    int bo = D_DESCALE(invc[6] * xv + invc[7] * yv + invc[8] * zv, shift);
+                    // |x|,|y|,|z| < 2^17 and |coefficient| < 2^14: 24-bit multiplies are exact
+                    int ro = D_DESCALE(__mul24(invc[0], xv) + __mul24(invc[1], yv) + __mul24(invc[2], zv), shift);
+                    int go = D_DESCALE(__mul24(invc[3], xv) + __mul24(invc[4], yv) + __mul24(invc[5], zv), shift);
+                    int bo = D_DESCALE(__mul24(invc[6], xv) + __mul24(invc[7], yv) + __mul24(invc[8], zv), shift);
                     ro = min(max(ro, 0), INV_GAMMA_TAB_SIZE - 1);
                     go = min(max(go, 0), INV_GAMMA_TAB_SIZE - 1);
                     bo = min(max(bo, 0), INV_GAMMA_TAB_SIZE - 1);
@@ -415,12 +417,11 @@ int launch_clahe_apply(cbv_ctx* ctx, const u8* lab, const u8* luts, u8* dst, Geo
 {
     const int rows_per_wg = 8;
     int tiles = cg.tiles_x * cg.tiles_y;
-    size_t lds = INV_GAMMA_TAB_SIZE * 2 + 1024 + 64 + 2 * (size_t)cg.tiles_x * 256;
-    if (lds > 64 * 1024) return cbv_fail(ctx, CBV_ERR_UNSUPPORTED, "clahe: tile grid too wide (%d)", cg.tiles_x);
+    if (cg.tiles_x > CLAHE_MAX_TILES_X) return cbv_fail(ctx, CBV_ERR_UNSUPPORTED, "clahe: tile grid wider than %d (%d)", CLAHE_MAX_TILES_X, cg.tiles_x);
     // a band is at most th rows (+1 for rounding)
     dim3 grid((cg.th + 1 + rows_per_wg - 1) / rows_per_wg, cg.tiles_y + 1, batch);
     prof_begin(ctx, CBV_K_CLAHE_APPLY);
-    hipLaunchKernelGGL(k_clahe_apply, grid, dim3(256), lds, ctx->stream, lab, luts, dst, g, cg, ctx->tabs, rows_per_wg,
+    hipLaunchKernelGGL(k_clahe_apply, grid, dim3(256), 0, ctx->stream, lab, luts, dst, g, cg, ctx->tabs, rows_per_wg,
                        tiles);
     prof_end(ctx, CBV_K_CLAHE_APPLY);
     CBV_HIP(ctx, hipGetLastError());

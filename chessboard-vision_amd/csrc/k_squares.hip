@@ -322,6 +322,8 @@ __global__ __launch_bounds__(256) void k_scan(const SquareDesc* __restrict__ des
     const int nvec = (n + 15) >> 4;
     ScanState st = state[sq];
     uint4 rv[SCAN_VPT], cur[SCAN_VPT], nxt[SCAN_VPT];
+#pragma unroll
+    for (int k = 0; k < SCAN_VPT; k++) nxt[k] = make_uint4(0, 0, 0, 0);
     const uint4* refv = (const uint4*)(ref + d.plane_off);
 #pragma unroll
     for (int k = 0; k < SCAN_VPT; k++) {
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(256) void k_scan(const SquareDesc* __restrict__ des
 #pragma unroll
             for (int k = 0; k < SCAN_VPT; k++) {
                 const int vi = threadIdx.x + k * 256;
-                if (vi < nvec) nxt[k] = gn[vi];
+                nxt[k] = vi < nvec ? gn[vi] : make_uint4(0, 0, 0, 0); // lanes past the plane must compare equal
             }
         }
         u32 sad = 0;

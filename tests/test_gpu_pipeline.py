@@ -1,0 +1,162 @@
+"""GPU parity of the composed, device-resident chain (stream.BoardPipeline):
+synthetic frames -> enhance -> warp -> 64-square detect with temporal logic,
+against the oracle chain on the same frames, plus the size-independent
+properties used at BASELINE.json's full sizes."""
+import numpy as np
+import pytest
+
+from chessboard_vision_amd import synth as S
+from helpers import oracle_frame
+
+pytestmark = pytest.mark.gpu
+
+W, H = 640, 480
+
+
+def _oracle_chain(oracle, frames, profile, pts, grid_lines=None):
+    from chessboard_vision_amd.grid_extractor import GridExtractor, SmartGridExtractor
+    from ref_logic import RefPieceDetector
+    ge = GridExtractor()
+    if grid_lines is not None:
+        ge = SmartGridExtractor()
+        ge.grid_lines_x, ge.grid_lines_y = list(grid_lines[0]), list(grid_lines[1])
+    det = RefPieceDetector()
+    out = []
+    for f in frames:
+        enh = oracle.process_pipeline(f, profile)
+        warped, _, _ = oracle.warp_image(enh, pts)
+        res, vis = det.detect_all_pieces(ge.split_board(warped))
+        out.append(dict(enh=enh, warped=warped, stable={p for p, r in res.items() if r["has_piece"]},
+                        raw={p for p, r in det.cached_results.items() if r["has_piece"]}, visual=set(vis)))
+    return out
+
+
+@pytest.mark.parametrize("scene,profile,grid", [("dim", S.SHIPPED_PROFILE, "smart"), ("normal", {}, "linear")])
+def test_pipeline_matches_oracle_chain(gpu_ctx, oracle, scene, profile, grid):
+    from chessboard_vision_amd.stream import BoardPipeline, bits_to_positions
+    n = 12
+    pts = S.scaled_corners(W, H)
+    gl = (S.CALIB_GRID_X, S.CALIB_GRID_Y) if grid == "smart" else None
+    p = BoardPipeline(W, H, n)
+    p.configure(pts, profile=profile, grid_lines=gl, keep_enhanced=True, chunk=5, lanes=2)
+    p.synth(0, n, stream_id=3, scene=scene, frames_per_ply=2)
+    frames = [oracle_frame(W, H, scene, stream_id=3, frame_idx=i, frames_per_ply=2) for i in range(n)]
+    for i in (0, 5, n - 1):
+        assert np.array_equal(p.download(0, i), frames[i]), "synthetic frame %d differs" % i
+    p.run(0, n)
+    res = p.results(0, n)
+    ref = _oracle_chain(oracle, frames, profile, pts, gl)
+    for i in range(n):
+        assert np.array_equal(p.download(1, i), ref[i]["enh"]), "enhanced frame %d" % i
+        assert np.array_equal(p.download(2, i), ref[i]["warped"]), "warped board %d" % i
+        assert bits_to_positions(res[i].stable_occupied, p.rois_rc) == ref[i]["stable"], i
+        assert bits_to_positions(res[i].raw_occupied, p.rois_rc) == ref[i]["raw"], i
+        assert bits_to_positions(res[i].visual_changes, p.rois_rc) == ref[i]["visual"], i
+        # raw occupancy is the scripted position of that frame -> FEN placement is bit-identical
+        assert ref[i]["raw"] == set(S.position_for_frame(i, 2).keys())
+
+
+def test_fused_and_unfused_paths_and_lane_counts_agree(gpu_ctx):
+    """normalize folded into the warp gather (bench path) == materialised enhanced frame; any chunk/lane split."""
+    from chessboard_vision_amd.stream import BoardPipeline
+    n = 9
+    pts = S.scaled_corners(W, H)
+    outs = []
+    for keep, chunk, lanes in ((True, 4, 1), (False, 4, 1), (False, 2, 3), (False, 9, 2)):
+        p = BoardPipeline(W, H, n)
+        p.configure(pts, profile=S.SHIPPED_PROFILE, keep_enhanced=keep, chunk=chunk, lanes=lanes)
+        p.synth(0, n, scene="dim", frames_per_ply=2)
+        p.run(0, n)
+        res = p.results(0, n)
+        outs.append(([p.download(2, i) for i in range(n)], [(r.raw_occupied, r.stable_occupied, r.visual_changes, r.processed) for r in res]))
+        p.close()
+    for o in outs[1:]:
+        for a, b in zip(outs[0][0], o[0]):
+            assert np.array_equal(a, b)
+        assert outs[0][1] == o[1]
+
+
+def test_state_carries_across_runs_and_resets(gpu_ctx):
+    from chessboard_vision_amd.stream import BoardPipeline
+    n = 10
+    pts = S.scaled_corners(W, H)
+    p = BoardPipeline(W, H, n)
+    p.configure(pts, profile={}, chunk=3)
+    p.synth(0, n, scene="normal", frames_per_ply=2)
+    p.run(0, n)
+    whole = [(r.raw_occupied, r.stable_occupied, r.visual_changes, r.processed) for r in p.results(0, n)]
+    p.reset_state()
+    p.run(0, 4)
+    p.run(4, 6)  # temporal state (references, cache, history) continues from the previous call
+    split = [(r.raw_occupied, r.stable_occupied, r.visual_changes, r.processed) for r in p.results(0, n)]
+    assert whole == split
+    assert whole[0][3] == 0xFFFFFFFFFFFFFFFF and whole[0][2] == 0xFFFFFFFFFFFFFFFF  # first frame: no reference yet
+
+
+def test_upload_path_equals_synth_path(gpu_ctx):
+    from chessboard_vision_amd.stream import BoardPipeline
+    pts = S.scaled_corners(W, H)
+    a, b = BoardPipeline(W, H, 2), BoardPipeline(W, H, 2)
+    for p in (a, b):
+        p.configure(pts, profile=S.SHIPPED_PROFILE)
+    a.synth(0, 2, scene="dim")
+    for i in range(2):
+        b.upload(i, oracle_frame(W, H, "dim", frame_idx=i))
+    a.run(0, 2)
+    b.run(0, 2)
+    assert [r.stable_occupied for r in a.results(0, 2)] == [r.stable_occupied for r in b.results(0, 2)]
+    assert np.array_equal(a.download(2, 1), b.download(2, 1))
+
+
+def test_full_size_properties_1080p(gpu_ctx, oracle):
+    """BASELINE.json full size (1080p stream): one frame exact against the oracle, then
+    size-independent properties over the stream: determinism, occupancy = scripted position."""
+    from chessboard_vision_amd.stream import BoardPipeline
+    w, h, n = 1920, 1080, 40
+    pts = S.scaled_corners(w, h)
+    p = BoardPipeline(w, h, n)
+    p.configure(pts, profile=S.SHIPPED_PROFILE, grid_lines=(S.CALIB_GRID_X, S.CALIB_GRID_Y), keep_enhanced=True, chunk=8)
+    p.synth(0, n, scene="dim", frames_per_ply=4)
+    p.run(0, n)
+    res = p.results(0, n)
+    f7 = oracle_frame(w, h, "dim", frame_idx=7, frames_per_ply=4)
+    assert np.array_equal(p.download(0, 7), f7)
+    enh = oracle.process_pipeline(f7, S.SHIPPED_PROFILE)
+    assert np.array_equal(p.download(1, 7), enh)
+    assert np.array_equal(p.download(2, 7), oracle.warp_image(enh, pts)[0])
+    for i in range(n):
+        assert p.occupied(res[i], stable=False) == set(S.position_for_frame(i, 4).keys()), i
+    first = [(r.raw_occupied, r.stable_occupied) for r in res]
+    p.reset_state()
+    p.run(0, n)
+    assert first == [(r.raw_occupied, r.stable_occupied) for r in p.results(0, n)]
+
+
+def test_4k_frame_config4(gpu_ctx, oracle):
+    """BASELINE.json configs[3]: 3840x2160, bilateral d = 9 (tile/halo stress)."""
+    from chessboard_vision_amd.frame_enhancer import ImageEnhancer
+    e = ImageEnhancer()
+    e.profile = S.SHIPPED_PROFILE
+    f = oracle_frame(3840, 2160, "dim")
+    out = e.process_pipeline(f)
+    assert np.array_equal(out, oracle.process_pipeline(f, S.SHIPPED_PROFILE))
+
+
+@pytest.mark.parametrize("size", [(9, 7), (16, 16), (33, 5), (5, 40), (131, 67)])
+def test_tiny_and_ragged_frames(gpu_ctx, oracle, size):
+    """Images smaller than a tile / a CLAHE grid cell / the bilateral radius."""
+    from chessboard_vision_amd.frame_enhancer import ImageEnhancer
+    w, h = size
+    rng = np.random.default_rng(w * 100 + h)
+    f = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+    e = ImageEnhancer()
+    e.profile = S.SHIPPED_PROFILE
+    assert np.array_equal(e.apply_color_profile(f), oracle.apply_color_profile(f, S.SHIPPED_PROFILE))
+    assert np.array_equal(e.correct_lighting(f), oracle.correct_lighting(f))
+    assert np.array_equal(e.reduce_noise(f), oracle.bilateral(f))
+    assert np.array_equal(e.sharpen(f), oracle.filter3x3(f))
+    assert np.array_equal(e.normalize_intensity(f), oracle.normalize_minmax(f))
+    g, b = e.prepare_analysis(f)
+    og, ob, _ = oracle.prepare_analysis(f)
+    assert np.array_equal(g, og) and np.array_equal(b, ob)
+    assert np.array_equal(e.process_pipeline(f), oracle.process_pipeline(f, S.SHIPPED_PROFILE))
