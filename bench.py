@@ -91,9 +91,10 @@ def main():
     import numpy as np
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ):  # launched by torch.distributed.run
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("NCCL_DEBUG", "WARN")  # keep RCCL's version banner off stdout: rank 0 prints ONE JSON line
         dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
     torch.cuda.set_device(local_rank)
 
@@ -228,7 +229,8 @@ def main():
             "kernels": kernels, "single_frame_ms": single_ms, "cpu_baseline": cpu, "occupancy_check": bool(occ_ok),
             "device": ctx.name,
         }
-        print(json.dumps(out))
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
