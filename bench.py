@@ -94,8 +94,20 @@ def main():
     if world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ):  # launched by torch.distributed.run
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("NCCL_DEBUG", "WARN")  # keep RCCL's version banner off stdout: rank 0 prints ONE JSON line
-        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
+        torch.cuda.set_device(local_rank)
+        # RCCL prints a version banner on fd 1 when the communicator is created; rank 0's stdout must
+        # carry ONE JSON line, so fd 1 points at stderr until the first collective has run.
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     torch.cuda.set_device(local_rank)
 
     from chessboard_vision_amd import _native as N
