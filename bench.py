@@ -132,6 +132,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ChangeDetector stage: background model captured from frame 0 (calibrate_sensitivity.py:150-152 does it
+    # at frame 30 of a live feed), then every frame is classified against it next to the piece detector
+    pipe.run(0, 1)
+    pipe.calibrate_changes(0)
+    pipe.reset_state()
     for _ in range(args.warmup):
         pipe.run(0, F)
     barrier()
@@ -166,6 +171,8 @@ def main():
         # one extra, untimed pass with events around every kernel, on ONE lane so that kernels of
         # different chunks do not overlap and each duration is the kernel's own
         pipe.configure(pts, profile=profile, grid_lines=grid, chunk=args.chunk, lanes=1)
+        pipe.run(0, 1)
+        pipe.calibrate_changes(0)
         pipe.run(0, F)
         torch.cuda.synchronize()
         ctx.profile_reset()
@@ -227,7 +234,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "configs[2]: %dx%d, %d frames in flight per GPU, enhance(profile+CLAHE+bilateral d=9+sharpen+"
-                                   "normalize)->warp 620x620->64-square detect (5-frame smoothing)" % (w, h, F),
+                                   "normalize)->warp 620x620->64-square change_detect (z-score model) + piece_detect (5-frame smoothing)" % (w, h, F),
                        "frames_per_step_per_gpu": F, "chunk": frames_per_launch, "streams": "one independent stream per GPU"},
             "roofline": {"bound": "hbm", "kernel": "k_bilateral", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": traffic,

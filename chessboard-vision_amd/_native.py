@@ -82,12 +82,13 @@ class PipelineConfig(C.Structure):
     _fields_ = [("enhance", EnhanceParams), ("M", C.c_double * 9), ("board_size", C.c_int32), ("rot180", C.c_int32),
                 ("n_rois", C.c_int32), ("rois", Roi * MAX_SQUARES), ("history_size", C.c_int32),
                 ("min_presence", C.c_double), ("change_threshold", C.c_double), ("chunk", C.c_int32),
-                ("lanes", C.c_int32), ("keep_enhanced", C.c_int32)]
+                ("lanes", C.c_int32), ("z_threshold", C.c_double), ("initial_variance", C.c_double), ("keep_enhanced", C.c_int32)]
 
 
 class FrameResult(C.Structure):
     _fields_ = [("raw_occupied", C.c_uint64), ("stable_occupied", C.c_uint64), ("visual_changes", C.c_uint64),
-                ("processed", C.c_uint64)]
+                ("processed", C.c_uint64), ("changed", C.c_uint64), ("parcial", C.c_uint64), ("total", C.c_uint64),
+                ("circular", C.c_uint64)]
 
 
 KERNEL_IDS = ["COLOR_LAB_HIST", "CLAHE_LUT", "CLAHE_APPLY", "BILATERAL", "SHARPEN", "NORM_LUT", "NORMALIZE", "WARP",
@@ -150,6 +151,7 @@ def load():
         "cbv_pipeline_upload": (i32, [vp, i32, u8p, i32]),
         "cbv_pipeline_synth": (i32, [vp, i32, i32, vp, vp, vp, P(Scene)]),
         "cbv_pipeline_reset_state": (i32, [vp]),
+        "cbv_pipeline_calibrate": (i32, [vp, i32]),
         "cbv_pipeline_run": (i32, [vp, i32, i32]),
         "cbv_pipeline_results": (i32, [vp, i32, i32, P(FrameResult)]),
         "cbv_pipeline_download": (i32, [vp, i32, i32, u8p]),

@@ -818,7 +818,8 @@ struct cbv_pipeline {
     u8* enhanced = nullptr; // [max_frames] when keep_enhanced
     u8* warped = nullptr;   // [max_frames][S][S][3]
     size_t warped_stride = 0;
-    DevBuf d_descs, d_masks, d_gray, d_stats, d_ref, d_state, d_results, d_coef, d_synth;
+    DevBuf d_descs, d_masks, d_gray, d_stats, d_ref, d_state, d_results, d_coef, d_synth, d_mean, d_var;
+    bool calibrated = false;
     std::vector<SquareDesc> descs;
     size_t plane_total = 0;
     bool keep_enhanced = false;
@@ -860,7 +861,7 @@ extern "C" void cbv_pipeline_destroy(cbv_pipeline* p)
     if (p->frames) (void)hipFree(p->frames);
     if (p->enhanced) (void)hipFree(p->enhanced);
     if (p->warped) (void)hipFree(p->warped);
-    DevBuf* bufs[] = {&p->d_descs, &p->d_masks, &p->d_gray, &p->d_stats, &p->d_ref, &p->d_state, &p->d_results, &p->d_coef, &p->d_synth};
+    DevBuf* bufs[] = {&p->d_descs, &p->d_masks, &p->d_gray, &p->d_stats, &p->d_ref, &p->d_state, &p->d_results, &p->d_coef, &p->d_synth, &p->d_mean, &p->d_var};
     for (auto b : bufs) dev_free(b);
     delete p;
 }
@@ -936,6 +937,9 @@ extern "C" int cbv_pipeline_configure(cbv_pipeline* p, const cbv_pipeline_config
     RC(dev_ensure(ctx, &p->d_gray, off * p->max_frames));
     RC(dev_ensure(ctx, &p->d_stats, sizeof(cbv_sq_stats) * n * p->max_frames));
     RC(dev_ensure(ctx, &p->d_ref, off));
+    RC(dev_ensure(ctx, &p->d_mean, off * 4));
+    RC(dev_ensure(ctx, &p->d_var, off * 4));
+    p->calibrated = false;
     RC(dev_ensure(ctx, &p->d_state, sizeof(ScanState) * n));
     RC(dev_ensure(ctx, &p->d_results, sizeof(cbv_frame_result) * p->max_frames));
     int coef[32] = {0};
@@ -958,6 +962,18 @@ extern "C" int cbv_pipeline_reset_state(cbv_pipeline* p)
     cbv_ctx* ctx = p->ctx;
     CBV_HIP(ctx, hipSetDevice(ctx->device));
     CBV_HIP(ctx, hipMemsetAsync(p->d_state.p, 0, sizeof(ScanState) * p->cfg.n_rois, ctx->stream));
+    return CBV_OK;
+}
+
+extern "C" int cbv_pipeline_calibrate(cbv_pipeline* p, int slot)
+{
+    if (!p || !p->configured) return CBV_ERR_STATE;
+    cbv_ctx* ctx = p->ctx;
+    if (slot < 0 || slot >= p->max_frames) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_pipeline_calibrate: bad slot");
+    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    RC(launch_squares_calibrate(ctx, (const SquareDesc*)p->d_descs.p, p->cfg.n_rois, (const u8*)p->d_gray.p + p->plane_total * slot,
+                                (float*)p->d_mean.p, (float*)p->d_var.p, (float)p->cfg.initial_variance, nullptr));
+    p->calibrated = true;
     return CBV_OK;
 }
 
@@ -1036,7 +1052,8 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
                                            (u8*)p->d_gray.p + p->plane_total * s0, p->plane_total, b);
         if (rc_all) break;
         rc_all = launch_squares_stats(ctx, (const SquareDesc*)p->d_descs.p, n, (const u8*)p->d_gray.p + p->plane_total * s0, p->plane_total,
-                                      nullptr, nullptr, nullptr, (const u8*)p->d_masks.p, 0.f, (cbv_sq_stats*)p->d_stats.p + (size_t)n * s0, b);
+                                      nullptr, p->calibrated ? (const float*)p->d_mean.p : nullptr, p->calibrated ? (const float*)p->d_var.p : nullptr,
+                                      (const u8*)p->d_masks.p, (float)cfg.z_threshold, (cbv_sq_stats*)p->d_stats.p + (size_t)n * s0, b);
     }
     ctx->stream = main_stream;
     if (rc_all) return rc_all;
@@ -1050,6 +1067,7 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
     sp.history_size = cfg.history_size;
     sp.min_presence = cfg.min_presence;
     sp.change_threshold = cfg.change_threshold;
+    sp.with_model = p->calibrated ? 1 : 0;
     RC(launch_scan(ctx, (const SquareDesc*)p->d_descs.p, sp, (const u8*)p->d_gray.p + p->plane_total * slot0, p->plane_total,
                    (const cbv_sq_stats*)p->d_stats.p + (size_t)n * slot0, (u8*)p->d_ref.p, (ScanState*)p->d_state.p,
                    (cbv_frame_result*)p->d_results.p + slot0, count));

@@ -199,6 +199,7 @@ struct ScanParams {
     int history_size;
     double min_presence;
     double change_threshold;
+    int with_model; // z_count of the statistics is valid: classify LEVE / PARCIAL / TOTAL
 };
 struct ScanState {       // per square, device resident
     u32 has_ref, has_cache, cached_raw, hist_len, hist_bits;

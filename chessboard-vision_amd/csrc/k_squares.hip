@@ -361,9 +361,15 @@ __global__ __launch_bounds__(256) void k_scan(const SquareDesc* __restrict__ des
             changed = mean_diff > sp.change_threshold;
         }
         const bool should_process = !st.has_cache || changed;
+        const cbv_sq_stats sst = stats[(size_t)t * sp.n + sq];
+        // change_detector.py:137-150: pct = (changed / total) * 100 as a Python float
+        const double pct = sp.with_model ? ((double)sst.z_count / (double)sst.n) * 100.0 : 0.0;
+        const bool in_changes = sp.with_model && !(pct < 5.0);
+        // detect_piece on the current square, only where one of the two detectors asks for it
+        const bool fresh = (should_process || in_changes) ? d_detect_piece(sst) : false;
         bool raw;
         if (should_process) {
-            raw = d_detect_piece(stats[(size_t)t * sp.n + sq]);
+            raw = fresh;
             st.cached_raw = raw;
             st.has_cache = 1;
         } else {
@@ -391,6 +397,12 @@ __global__ __launch_bounds__(256) void k_scan(const SquareDesc* __restrict__ des
             if (stable) atomicOr((unsigned long long*)&r->stable_occupied, bit);
             if (changed) atomicOr((unsigned long long*)&r->visual_changes, bit);
             if (should_process) atomicOr((unsigned long long*)&r->processed, bit);
+            if (in_changes) {
+                atomicOr((unsigned long long*)&r->changed, bit);
+                if (pct > 75.0) atomicOr((unsigned long long*)&r->total, bit);
+                else if (pct > 15.0) atomicOr((unsigned long long*)&r->parcial, bit);
+                if (fresh) atomicOr((unsigned long long*)&r->circular, bit);
+            }
         }
 #pragma unroll
         for (int k = 0; k < SCAN_VPT; k++) cur[k] = nxt[k];

@@ -44,7 +44,7 @@ class BoardPipeline:
 
     def configure(self, points, profile=None, grid_lines=None, rot180=False, chunk=0, lanes=0, keep_enhanced=False,
                   clahe_clip_limit=3.0, tile_grid_size=(8, 8), sharpen_kernel=None, display_size=(1280, 720), margin=100,
-                  history_size=5, min_presence=0.6, change_threshold=25):
+                  history_size=5, min_presence=0.6, change_threshold=25, z_threshold=2.5, initial_variance=100):
         cfg = N.PipelineConfig()
         e = cfg.enhance
         e.profile = N.ColorProfile.from_dict(profile)
@@ -73,6 +73,7 @@ class BoardPipeline:
             self.rois_rc.append((r, c))
         cfg.history_size, cfg.min_presence, cfg.change_threshold = history_size, min_presence, change_threshold
         cfg.chunk, cfg.lanes, cfg.keep_enhanced = chunk, lanes, 1 if keep_enhanced else 0
+        cfg.z_threshold, cfg.initial_variance = z_threshold, initial_variance
         self.ctx.check(self.ctx.lib.cbv_pipeline_configure(self.h_, cfg))
         self.board_size = S_
         self.matrix = M
@@ -99,6 +100,24 @@ class BoardPipeline:
 
     def reset_state(self):
         self.ctx.check(self.ctx.lib.cbv_pipeline_reset_state(self.h_))
+
+    def calibrate_changes(self, slot):
+        """ChangeDetector.calibrate from an already processed slot: later runs also classify
+        every square's change (LEVE / PARCIAL / TOTAL) against that background model."""
+        self.ctx.check(self.ctx.lib.cbv_pipeline_calibrate(self.h_, slot))
+
+    def changes_detailed(self, result, slot):
+        """The dict ChangeDetector.detect_changes_detailed returns (change_detector.py:105-167) for one frame."""
+        st = self.square_stats(slot)
+        out = {}
+        for i, (r, c) in enumerate(self.rois_rc):
+            if not (result.changed >> i) & 1:
+                continue
+            pct = (st[i].z_count / st[i].n) * 100
+            inten = "TOTAL" if (result.total >> i) & 1 else ("PARCIAL" if (result.parcial >> i) & 1 else "LEVE")
+            out[(c, 7 - r)] = {"z_score": float(st[i].z_max), "pct_changed": pct, "intensity": inten,
+                               "is_circular": bool((result.circular >> i) & 1), "center_ratio": 1.0}
+        return out
 
     def run(self, slot0, count):
         """Asynchronous on the context's stream."""

@@ -209,6 +209,10 @@ typedef struct {
     double change_threshold;     /* 25  piece_detector.py:50 */
     int32_t chunk;               /* frames per kernel launch (0 = default) */
     int32_t lanes;               /* HIP streams the chunks are spread over (0 = default 2, max 4) */
+    /* ChangeDetector stage on the same squares (change_detector.py:105-167), active once
+     * cbv_pipeline_calibrate() has captured the background model: */
+    double z_threshold;          /* 2.5  change_detector.py:23 */
+    double initial_variance;     /* 100  change_detector.py:24 */
     int32_t keep_enhanced;       /* 1: materialise process_pipeline's output per frame (cbv_pipeline_download
                                     which = 1); 0: fold the final normalize into the warp gather */
 } cbv_pipeline_config;
@@ -221,6 +225,11 @@ typedef struct {
     uint64_t stable_occupied;  /* after 5-frame smoothing = results[pos]['has_piece'] */
     uint64_t visual_changes;   /* _has_changed */
     uint64_t processed;        /* should_process */
+    /* ChangeDetector.detect_changes_detailed on the same frame (zero until calibrated): */
+    uint64_t changed;          /* pct_changed >= 5: the square is in the result dict */
+    uint64_t parcial;          /* 15 < pct_changed <= 75 */
+    uint64_t total;            /* pct_changed > 75 */
+    uint64_t circular;         /* detect_piece(current square)['has_piece'], evaluated fresh */
 } cbv_frame_result;
 
 CBV_API int cbv_pipeline_create(cbv_ctx* ctx, int w, int h, int max_frames, cbv_pipeline** out);
@@ -234,6 +243,9 @@ CBV_API int cbv_pipeline_synth(cbv_pipeline* p, int slot0, int count, const uint
                        const uint8_t* boards /* count*64 */, const cbv_scene* scene);
 /* reset the temporal detector state (reference squares, cache, history) */
 CBV_API int cbv_pipeline_reset_state(cbv_pipeline* p);
+/* ChangeDetector.calibrate (change_detector.py:36-47) from a slot that a previous cbv_pipeline_run
+ * has processed: mean = its preprocessed squares, variance = cfg.initial_variance. */
+CBV_API int cbv_pipeline_calibrate(cbv_pipeline* p, int slot);
 /* enqueue enhance -> warp -> detect for frames [slot0, slot0+count) in stream order; asynchronous */
 CBV_API int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count);
 CBV_API int cbv_pipeline_results(cbv_pipeline* p, int slot0, int count, cbv_frame_result* out);

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_the_header():
     from chessboard_vision_amd import _native as N
     assert C.sizeof(N.ColorProfile) == 72 and C.sizeof(N.SqStats) == 72 and C.sizeof(N.Roi) == 16
-    assert C.sizeof(N.FrameResult) == 32 and C.sizeof(N.Scene) == 32
+    assert C.sizeof(N.FrameResult) == 64 and C.sizeof(N.Scene) == 32
     assert C.sizeof(N.EnhanceParams) == 72 + 8 + 8 + 8 + 16 + 36 + 4
 
 

@@ -160,3 +160,36 @@ def test_tiny_and_ragged_frames(gpu_ctx, oracle, size):
     og, ob, _ = oracle.prepare_analysis(f)
     assert np.array_equal(g, og) and np.array_equal(b, ob)
     assert np.array_equal(e.process_pipeline(f), oracle.process_pipeline(f, S.SHIPPED_PROFILE))
+
+
+def test_pipeline_change_detector_stage(gpu_ctx, oracle):
+    """enhance -> warp -> change_detect + piece_detect in one device pass: the ChangeDetector stage
+    (calibrate on an early frame, then detect_changes_detailed per frame) against the oracle-side
+    restatement of change_detector.py on the same warped boards."""
+    from chessboard_vision_amd.grid_extractor import GridExtractor
+    from chessboard_vision_amd.stream import BoardPipeline
+    from ref_logic import RefChangeDetector
+    n = 10
+    pts = S.scaled_corners(W, H)
+    p = BoardPipeline(W, H, n)
+    p.configure(pts, profile={}, keep_enhanced=True, chunk=4, z_threshold=2.55, initial_variance=600)
+    p.synth(0, n, scene="normal", frames_per_ply=2)
+    p.run(0, 1)
+    p.calibrate_changes(0)
+    p.reset_state()
+    p.run(0, n)
+    res = p.results(0, n)
+    ref = RefChangeDetector()
+    ref.z_threshold, ref.initial_variance = 2.55, 600
+    seen = set()
+    for i in range(n):
+        f = oracle_frame(W, H, "normal", frame_idx=i, frames_per_ply=2)
+        warped, _, _ = oracle.warp_image(oracle.process_pipeline(f, {}), pts)
+        sq = GridExtractor().split_board(warped)
+        if i == 0:
+            ref.calibrate(sq)
+        exp = ref.detect_changes_detailed(sq)
+        got = p.changes_detailed(res[i], i)
+        assert got == exp, (i, got, exp)
+        seen |= {v["intensity"] for v in exp.values()}
+    assert "TOTAL" in seen or "PARCIAL" in seen  # the scripted moves do change squares
