@@ -331,8 +331,10 @@ __global__ __launch_bounds__(256) void k_scan(const SquareDesc* __restrict__ des
         rv[k] = (st.has_ref && vi < nvec) ? refv[vi] : make_uint4(0, 0, 0, 0);
         cur[k] = vi < nvec ? ((const uint4*)(gray + d.plane_off))[vi] : make_uint4(0, 0, 0, 0);
     }
+    cbv_sq_stats sst = stats[sq], nst = stats[sq];
     for (int t = 0; t < count; t++) {
         if (t + 1 < count) {
+            nst = stats[(size_t)(t + 1) * sp.n + sq]; // next frame's statistics and plane are fetched one step ahead
             const uint4* gn = (const uint4*)(gray + (size_t)(t + 1) * gray_frame_stride + d.plane_off);
 #pragma unroll
             for (int k = 0; k < SCAN_VPT; k++) {
@@ -361,7 +363,6 @@ __global__ __launch_bounds__(256) void k_scan(const SquareDesc* __restrict__ des
             changed = mean_diff > sp.change_threshold;
         }
         const bool should_process = !st.has_cache || changed;
-        const cbv_sq_stats sst = stats[(size_t)t * sp.n + sq];
         // change_detector.py:137-150: pct = (changed / total) * 100 as a Python float
         const double pct = sp.with_model ? ((double)sst.z_count / (double)sst.n) * 100.0 : 0.0;
         const bool in_changes = sp.with_model && !(pct < 5.0);
@@ -406,6 +407,7 @@ __global__ __launch_bounds__(256) void k_scan(const SquareDesc* __restrict__ des
         }
 #pragma unroll
         for (int k = 0; k < SCAN_VPT; k++) cur[k] = nxt[k];
+        sst = nst;
     }
     if (st.has_ref) {
         uint4* refw = (uint4*)(ref + d.plane_off);
