@@ -606,7 +606,7 @@ __global__ __launch_bounds__(256) void k_sharpen_box(const u8* __restrict__ src,
 
     const int lc = threadIdx.x & 63, rq = threadIdx.x >> 6; // 64 chunks of 16 B x 4 row quads
     const int x0 = xb0 + lc * 16;
-    float vmin = 3.0e38f, vmax = -3.0e38f;
+    int imin = 255, imax = 0;
     if (x0 < wb) {
         const int nbytes = min(16, wb - x0);
         float h[3][16]; // horizontal 3-sums of the last three staged rows
@@ -639,11 +639,25 @@ __global__ __launch_bounds__(256) void k_sharpen_box(const u8* __restrict__ src,
                     for (int k = 0; k < 16; k++) {
                         const float S = (h[0][k] + h[1][k]) + h[2][k];
                         const float v = __fmaf_rn(ca, c[(r - 1) & 1][k], a * S);
-                        if (k < nbytes) {
-                            vmin = fminf(vmin, v);
-                            vmax = fmaxf(vmax, v);
-                        }
                         o[k >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(v, k & 3, o[k >> 2]);
+                    }
+                    // min/max of the saturated bytes, in integers (byte operands are free with SDWA; f32
+                    // min/max would pay a canonicalisation each)
+                    if (nbytes == 16) {
+#pragma unroll
+                        for (int k = 0; k < 16; k++) {
+                            const int bv = (int)((o[k >> 2] >> ((k & 3) * 8)) & 255u);
+                            imin = min(imin, bv);
+                            imax = max(imax, bv);
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 16; k++)
+                            if (k < nbytes) {
+                                const int bv = (int)((o[k >> 2] >> ((k & 3) * 8)) & 255u);
+                                imin = min(imin, bv);
+                                imax = max(imax, bv);
+                            }
                     }
                     u8* q = df + (size_t)yo * g.stride + x0;
                     if (nbytes == 16 && al16) *(uint4*)q = make_uint4(o[0], o[1], o[2], o[3]);
@@ -653,13 +667,7 @@ __global__ __launch_bounds__(256) void k_sharpen_box(const u8* __restrict__ src,
             }
         }
     }
-    int mn = (int)fminf(fmaxf(vmin, 0.f), 255.f), mx = (int)fminf(fmaxf(vmax, 0.f), 255.f);
-    if (vmin > vmax) { // lane produced nothing
-        mn = 255;
-        mx = 0;
-    }
-    mn = wave_min_i32(mn);
-    mx = wave_max_i32(mx);
+    const int mn = wave_min_i32(imin), mx = wave_max_i32(imax);
     if ((threadIdx.x & 63) == 0) {
         red[rq] = mn;
         red[4 + rq] = mx;
