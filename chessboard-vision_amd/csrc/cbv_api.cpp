@@ -818,7 +818,7 @@ struct cbv_pipeline {
     u8* enhanced = nullptr; // [max_frames] when keep_enhanced
     u8* warped = nullptr;   // [max_frames][S][S][3]
     size_t warped_stride = 0;
-    DevBuf d_descs, d_masks, d_gray, d_stats, d_ref, d_state, d_results, d_coef, d_synth, d_mean, d_var;
+    DevBuf d_descs, d_masks, d_gray, d_stats, d_ref, d_state, d_results, d_flags, d_dec, d_coef, d_synth, d_mean, d_var;
     bool calibrated = false;
     std::vector<SquareDesc> descs;
     size_t plane_total = 0;
@@ -861,7 +861,7 @@ extern "C" void cbv_pipeline_destroy(cbv_pipeline* p)
     if (p->frames) (void)hipFree(p->frames);
     if (p->enhanced) (void)hipFree(p->enhanced);
     if (p->warped) (void)hipFree(p->warped);
-    DevBuf* bufs[] = {&p->d_descs, &p->d_masks, &p->d_gray, &p->d_stats, &p->d_ref, &p->d_state, &p->d_results, &p->d_coef, &p->d_synth, &p->d_mean, &p->d_var};
+    DevBuf* bufs[] = {&p->d_descs, &p->d_masks, &p->d_gray, &p->d_stats, &p->d_ref, &p->d_state, &p->d_results, &p->d_flags, &p->d_dec, &p->d_coef, &p->d_synth, &p->d_mean, &p->d_var};
     for (auto b : bufs) dev_free(b);
     delete p;
 }
@@ -875,7 +875,7 @@ extern "C" int cbv_pipeline_configure(cbv_pipeline* p, const cbv_pipeline_config
     CBV_HIP(ctx, hipSetDevice(ctx->device));
     if (cfg->n_rois <= 0 || cfg->n_rois > CBV_MAX_SQUARES || cfg->board_size <= 0 || cfg->board_size > 4096)
         return cbv_fail(ctx, CBV_ERR_ARG, "cbv_pipeline_configure: bad board/roi configuration");
-    if (cfg->history_size < 1 || cfg->history_size > 31) return cbv_fail(ctx, CBV_ERR_ARG, "history_size must be in 1..31");
+    if (cfg->history_size < 1 || cfg->history_size > 7) return cbv_fail(ctx, CBV_ERR_ARG, "history_size must be in 1..7");
     RC(check_params(ctx, &cfg->enhance));
     CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     p->cfg = *cfg;
@@ -942,6 +942,8 @@ extern "C" int cbv_pipeline_configure(cbv_pipeline* p, const cbv_pipeline_config
     p->calibrated = false;
     RC(dev_ensure(ctx, &p->d_state, sizeof(ScanState) * n));
     RC(dev_ensure(ctx, &p->d_results, sizeof(cbv_frame_result) * p->max_frames));
+    RC(dev_ensure(ctx, &p->d_flags, (size_t)CBV_MAX_SQUARES * p->max_frames));
+    RC(dev_ensure(ctx, &p->d_dec, (size_t)CBV_MAX_SQUARES * p->max_frames));
     int coef[32] = {0};
     build_gaussian_q8(5, coef);
     RC(dev_ensure(ctx, &p->d_coef, sizeof(coef)));
@@ -1053,7 +1055,8 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
         if (rc_all) break;
         rc_all = launch_squares_stats(ctx, (const SquareDesc*)p->d_descs.p, n, (const u8*)p->d_gray.p + p->plane_total * s0, p->plane_total,
                                       nullptr, p->calibrated ? (const float*)p->d_mean.p : nullptr, p->calibrated ? (const float*)p->d_var.p : nullptr,
-                                      (const u8*)p->d_masks.p, (float)cfg.z_threshold, (cbv_sq_stats*)p->d_stats.p + (size_t)n * s0, b);
+                                      (const u8*)p->d_masks.p, (float)cfg.z_threshold, (cbv_sq_stats*)p->d_stats.p + (size_t)n * s0, b,
+                                      (u8*)p->d_dec.p + (size_t)CBV_MAX_SQUARES * s0);
     }
     ctx->stream = main_stream;
     if (rc_all) return rc_all;
@@ -1061,16 +1064,21 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
         CBV_HIP(ctx, hipEventRecord(p->lane_done[l], p->lane_stream[l]));
         CBV_HIP(ctx, hipStreamWaitEvent(main_stream, p->lane_done[l], 0));
     }
-    CBV_HIP(ctx, hipMemsetAsync((cbv_frame_result*)p->d_results.p + slot0, 0, sizeof(cbv_frame_result) * count, ctx->stream));
     ScanParams sp;
     sp.n = n;
     sp.history_size = cfg.history_size;
     sp.min_presence = cfg.min_presence;
     sp.change_threshold = cfg.change_threshold;
     sp.with_model = p->calibrated ? 1 : 0;
+    sp.stable_table = 0;
+    for (int len = 1; len <= 7 && len <= cfg.history_size; len++)
+        for (int sum = 0; sum <= len; sum++)
+            if ((double)sum / (double)len >= cfg.min_presence) sp.stable_table |= 1ull << (len * 8 + sum);
+    sp.thr_is_int = (cfg.change_threshold == (double)(int)cfg.change_threshold && cfg.change_threshold >= 0 && cfg.change_threshold < 256) ? 1 : 0;
+    sp.thr_int = (int)cfg.change_threshold;
     RC(launch_scan(ctx, (const SquareDesc*)p->d_descs.p, sp, (const u8*)p->d_gray.p + p->plane_total * slot0, p->plane_total,
-                   (const cbv_sq_stats*)p->d_stats.p + (size_t)n * slot0, (u8*)p->d_ref.p, (ScanState*)p->d_state.p,
-                   (cbv_frame_result*)p->d_results.p + slot0, count));
+                   (const u8*)p->d_dec.p + (size_t)CBV_MAX_SQUARES * slot0, (u8*)p->d_ref.p, (ScanState*)p->d_state.p,
+                   (u8*)p->d_flags.p + (size_t)CBV_MAX_SQUARES * slot0, (cbv_frame_result*)p->d_results.p + slot0, count));
     return CBV_OK;
 }
 

@@ -187,7 +187,7 @@ int launch_squares_preprocess(cbv_ctx* ctx, const u8* src, size_t src_frame_stri
                               const int* coef_dev, int blur_k, u8* gray, size_t gray_frame_stride, int batch);
 int launch_squares_stats(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, size_t gray_frame_stride,
                          const u8* ref, const float* mean, const float* var, const u8* masks, float z_thresh,
-                         cbv_sq_stats* out, int batch);
+                         cbv_sq_stats* out, int batch, u8* decisions = nullptr);
 int launch_squares_calibrate(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, float* mean, float* var,
                              float init_var, const u8* select);
 int launch_squares_ema(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, float* mean, float* var,
@@ -200,9 +200,15 @@ struct ScanParams {
     double min_presence;
     double change_threshold;
     int with_model; // z_count of the statistics is valid: classify LEVE / PARCIAL / TOTAL
+    // _get_stable_detection's `sum(history) / len(history) >= min_presence` evaluated on the host in double for
+    // every (len, sum): bit len * 8 + sum
+    u64 stable_table;
+    // mean(|diff|) > change_threshold as an exact integer test when the threshold is integral: sad > thr * n
+    int thr_is_int;
+    int thr_int;
 };
 struct ScanState {       // per square, device resident
     u32 has_ref, has_cache, cached_raw, hist_len, hist_bits;
 };
 int launch_scan(cbv_ctx* ctx, const SquareDesc* descs, ScanParams sp, const u8* gray, size_t gray_frame_stride,
-                const cbv_sq_stats* stats, u8* ref, ScanState* state, cbv_frame_result* results, int count);
+                const u8* decisions, u8* ref, ScanState* state, u8* flags, cbv_frame_result* results, int count);

@@ -111,11 +111,44 @@ int launch_squares_preprocess(cbv_ctx* ctx, const u8* src, size_t src_frame_stri
 }
 
 // ---------------------------------------------------------------------------
+// PieceDetector.detect_piece decision chain without HoughCircles
+// (piece_detector.py:303-345), evaluated in double like numpy does.
+// ---------------------------------------------------------------------------
+__device__ bool d_detect_piece(const cbv_sq_stats& st)
+{
+    // np.std(gray) < 15  <=>  n*sumsq - sum^2 < 225 n^2   (exact integer form)
+    const long long n = st.n, s = st.sum;
+    const long long lhs = n * (long long)st.sumsq - s * s;
+    if (lhs < 225ll * n * n) return false;
+    const double cm = (double)st.center_sum / (double)st.center_cnt;
+    const double bm = (double)st.border_sum / (double)st.border_cnt;
+    const double diff = fabs(cm - bm);
+    if (diff > 40.0) return true;
+    double rm[4];
+    int nr = 0;
+    for (int k = 0; k < 4; k++)
+        if (st.ring_cnt[k] > 0) rm[nr++] = (double)st.ring_sum[k] / (double)st.ring_cnt[k];
+    if (nr < 2) return false;
+    double sum = 0;
+    for (int k = 0; k < nr; k++) sum = sum + rm[k];
+    const double mean = sum / nr;
+    double sq = 0;
+    for (int k = 0; k < nr; k++) {
+        const double x = rm[k] - mean;
+        sq = sq + x * x;
+    }
+    const double variance = sq / nr;
+    const double score = fmin(1.0, variance / 500.0);
+    return score > 0.6;
+}
+
+// ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_squares_stats(const SquareDesc* __restrict__ descs,
                                                         const u8* __restrict__ gray, size_t gray_frame_stride,
                                                         const u8* __restrict__ ref, const float* __restrict__ mean,
                                                         const float* __restrict__ var, const u8* __restrict__ masks,
-                                                        float z_thresh, cbv_sq_stats* __restrict__ out, int nsq)
+                                                        float z_thresh, cbv_sq_stats* __restrict__ out, int nsq,
+                                                        u8* __restrict__ decisions)
 {
     __shared__ u32 acc[20];
     __shared__ float zm[4];
@@ -184,16 +217,26 @@ __global__ __launch_bounds__(256) void k_squares_stats(const SquareDesc* __restr
         float z = fmaxf(fmaxf(zm[0], zm[1]), fmaxf(zm[2], zm[3]));
         st.z_max = nanf_[0] ? __builtin_nanf("") : z;
         out[(size_t)blockIdx.z * nsq + blockIdx.x] = st;
+        if (decisions) {
+            // the frame-parallel part of both detectors' decisions, so the sequential scan only does integer work:
+            // bit0 detect_piece(square), bits 1-3 ChangeDetector class (in dict / PARCIAL / TOTAL)
+            u32 dc = d_detect_piece(st) ? 1u : 0u;
+            if (mean) {
+                const double pct = ((double)st.z_count / (double)st.n) * 100.0; // change_detector.py:139 as a Python float
+                if (!(pct < 5.0)) dc |= 2u | (pct > 75.0 ? 8u : (pct > 15.0 ? 4u : 0u));
+            }
+            decisions[(size_t)blockIdx.z * CBV_MAX_SQUARES + blockIdx.x] = (u8)dc;
+        }
     }
 }
 
 int launch_squares_stats(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, size_t gray_frame_stride,
                          const u8* ref, const float* mean, const float* var, const u8* masks, float z_thresh,
-                         cbv_sq_stats* out, int batch)
+                         cbv_sq_stats* out, int batch, u8* decisions)
 {
     prof_begin(ctx, CBV_K_SQUARES);
     hipLaunchKernelGGL(k_squares_stats, dim3(n, 1, batch), dim3(256), 0, ctx->stream, descs, gray, gray_frame_stride,
-                       ref, mean, var, masks, z_thresh, out, n);
+                       ref, mean, var, masks, z_thresh, out, n, decisions);
     prof_end(ctx, CBV_K_SQUARES);
     CBV_HIP(ctx, hipGetLastError());
     return CBV_OK;
@@ -268,38 +311,6 @@ int launch_squares_set_ref(cbv_ctx* ctx, const SquareDesc* descs, int n, const u
     return CBV_OK;
 }
 
-// ---------------------------------------------------------------------------
-// PieceDetector.detect_piece decision chain without HoughCircles
-// (piece_detector.py:303-345), evaluated in double like numpy does.
-// ---------------------------------------------------------------------------
-__device__ bool d_detect_piece(const cbv_sq_stats& st)
-{
-    // np.std(gray) < 15  <=>  n*sumsq - sum^2 < 225 n^2   (exact integer form)
-    const long long n = st.n, s = st.sum;
-    const long long lhs = n * (long long)st.sumsq - s * s;
-    if (lhs < 225ll * n * n) return false;
-    const double cm = (double)st.center_sum / (double)st.center_cnt;
-    const double bm = (double)st.border_sum / (double)st.border_cnt;
-    const double diff = fabs(cm - bm);
-    if (diff > 40.0) return true;
-    double rm[4];
-    int nr = 0;
-    for (int k = 0; k < 4; k++)
-        if (st.ring_cnt[k] > 0) rm[nr++] = (double)st.ring_sum[k] / (double)st.ring_cnt[k];
-    if (nr < 2) return false;
-    double sum = 0;
-    for (int k = 0; k < nr; k++) sum = sum + rm[k];
-    const double mean = sum / nr;
-    double sq = 0;
-    for (int k = 0; k < nr; k++) {
-        const double x = rm[k] - mean;
-        sq = sq + x * x;
-    }
-    const double variance = sq / nr;
-    const double score = fmin(1.0, variance / 500.0);
-    return score > 0.6;
-}
-
 // detect_all_pieces(use_smoothing=True, use_delta=True, squares_to_check=None)
 // (piece_detector.py:348-440) over `count` consecutive frames; one workgroup
 // per square, state carried in ScanState and `ref`.
@@ -308,124 +319,143 @@ __device__ bool d_detect_piece(const cbv_sq_stats& st)
 // zero-padded), the reference lives in registers, the next frame's plane is
 // prefetched while the current one is reduced, and one barrier per frame
 // (double-buffered partial sums) is all the synchronisation there is.
-#define SCAN_VPT 4 // 16-byte vectors per lane: 256 lanes x 4 x 16 B = 128 x 128 px
-__global__ __launch_bounds__(256) void k_scan(const SquareDesc* __restrict__ descs, ScanParams sp,
-                                               const u8* __restrict__ gray, size_t gray_frame_stride,
-                                               const cbv_sq_stats* __restrict__ stats, u8* __restrict__ ref,
-                                               ScanState* __restrict__ state, cbv_frame_result* __restrict__ results,
-                                               int count)
+// One WAVE per square: the per-frame reduction is six DPP steps, there is no LDS and no barrier on
+// the critical path of the 512-step chain.
+
+template <int VPT, int SCAN_DEPTH>
+__device__ __forceinline__ void scan_body(const SquareDesc d, const ScanParams sp, const u8* __restrict__ gray,
+                                          size_t gray_frame_stride, const u8* __restrict__ decisions,
+                                          u8* __restrict__ ref, ScanState* __restrict__ state,
+                                          u8* __restrict__ flags, int count)
 {
-    __shared__ u32 red[2][4];
     const int sq = blockIdx.x;
-    const SquareDesc d = descs[sq];
     const int n = d.w * d.h;
     const int nvec = (n + 15) >> 4;
     ScanState st = state[sq];
-    uint4 rv[SCAN_VPT], cur[SCAN_VPT], nxt[SCAN_VPT];
-#pragma unroll
-    for (int k = 0; k < SCAN_VPT; k++) nxt[k] = make_uint4(0, 0, 0, 0);
+    uint4 rv[VPT], ring[SCAN_DEPTH][VPT];
+    u32 sring[SCAN_DEPTH];
     const uint4* refv = (const uint4*)(ref + d.plane_off);
+    auto fetch = [&](int t, uint4* dst, u32& sdst) {
+        const uint4* gp = (const uint4*)(gray + (size_t)t * gray_frame_stride + d.plane_off);
 #pragma unroll
-    for (int k = 0; k < SCAN_VPT; k++) {
-        const int vi = threadIdx.x + k * 256;
+        for (int k = 0; k < VPT; k++) {
+            const int vi = threadIdx.x + k * 64;
+            dst[k] = vi < nvec ? gp[vi] : make_uint4(0, 0, 0, 0); // lanes past the plane must compare equal
+        }
+        sdst = decisions[(size_t)t * CBV_MAX_SQUARES + sq];
+    };
+#pragma unroll
+    for (int k = 0; k < VPT; k++) {
+        const int vi = threadIdx.x + k * 64;
         rv[k] = (st.has_ref && vi < nvec) ? refv[vi] : make_uint4(0, 0, 0, 0);
-        cur[k] = vi < nvec ? ((const uint4*)(gray + d.plane_off))[vi] : make_uint4(0, 0, 0, 0);
     }
-    cbv_sq_stats sst = stats[sq], nst = stats[sq];
-    for (int t = 0; t < count; t++) {
-        if (t + 1 < count) {
-            nst = stats[(size_t)(t + 1) * sp.n + sq]; // next frame's statistics and plane are fetched one step ahead
-            const uint4* gn = (const uint4*)(gray + (size_t)(t + 1) * gray_frame_stride + d.plane_off);
 #pragma unroll
-            for (int k = 0; k < SCAN_VPT; k++) {
-                const int vi = threadIdx.x + k * 256;
-                nxt[k] = vi < nvec ? gn[vi] : make_uint4(0, 0, 0, 0); // lanes past the plane must compare equal
+    for (int j = 0; j < SCAN_DEPTH; j++)
+        if (j < count) fetch(j, ring[j], sring[j]);
+    for (int t0 = 0; t0 < count; t0 += SCAN_DEPTH) {
+#pragma unroll
+        for (int j = 0; j < SCAN_DEPTH; j++) {
+            const int t = t0 + j;
+            if (t >= count) break;
+            uint4 cur[VPT];
+#pragma unroll
+            for (int k = 0; k < VPT; k++) cur[k] = ring[j][k];
+            const u32 dc = sring[j];
+            if (t + SCAN_DEPTH < count) fetch(t + SCAN_DEPTH, ring[j], sring[j]);
+            u32 sad = 0;
+            if (st.has_ref) {
+#pragma unroll
+                for (int k = 0; k < VPT; k++) {
+                    sad = __builtin_amdgcn_sad_u8(cur[k].x, rv[k].x, sad);
+                    sad = __builtin_amdgcn_sad_u8(cur[k].y, rv[k].y, sad);
+                    sad = __builtin_amdgcn_sad_u8(cur[k].z, rv[k].z, sad);
+                    sad = __builtin_amdgcn_sad_u8(cur[k].w, rv[k].w, sad);
+                }
+            }
+            // every lane evaluates the (cheap, uniform) decision chain
+            const u32 tot = wave_sum_u32(sad);
+            bool changed = true;
+            if (st.has_ref) {
+                // np.mean(diff) > threshold; with an integral threshold t this is exactly sad > t * n
+                // (|sad - t n| >= 1 keeps the quotient far from t compared with an ulp)
+                if (sp.thr_is_int) changed = (long long)tot > (long long)sp.thr_int * n;
+                else changed = (double)tot / (double)n > sp.change_threshold;
+            }
+            const bool should_process = !st.has_cache || changed;
+            const bool in_changes = sp.with_model && (dc & 2u);
+            const bool fresh = (dc & 1u) != 0; // detect_piece on the current square (evaluated by k_squares_stats)
+            bool raw;
+            if (should_process) {
+                raw = fresh;
+                st.cached_raw = raw;
+                st.has_cache = 1;
+            } else {
+                raw = st.cached_raw != 0;
+            }
+            // _update_history / _get_stable_detection
+            st.hist_bits = (st.hist_bits << 1) | (raw ? 1u : 0u);
+            if ((int)st.hist_len < sp.history_size) st.hist_len++;
+            st.hist_bits &= (1u << st.hist_len) - 1u;
+            const bool stable = st.hist_len < 3 ? raw : ((sp.stable_table >> (st.hist_len * 8 + __popc(st.hist_bits))) & 1) != 0;
+            if (should_process && (raw == stable)) {
+#pragma unroll
+                for (int k = 0; k < VPT; k++) rv[k] = cur[k];
+                st.has_ref = 1;
+            }
+            if (threadIdx.x == 0) {
+                // one plain byte store per square and frame (64 workgroups hitting the same result words with
+                // atomics would queue behind each other AND in front of this wave's prefetches: vmcnt is in order)
+                u32 fl = (raw ? 1u : 0u) | (stable ? 2u : 0u) | (changed ? 4u : 0u) | (should_process ? 8u : 0u);
+                if (in_changes) fl |= 16u | ((dc & 8u) ? 64u : ((dc & 4u) ? 32u : 0u)) | (fresh ? 128u : 0u);
+                flags[(size_t)t * CBV_MAX_SQUARES + sq] = (u8)fl;
             }
         }
-        u32 sad = 0;
-        if (st.has_ref) {
-#pragma unroll
-            for (int k = 0; k < SCAN_VPT; k++) {
-                sad = __builtin_amdgcn_sad_u8(cur[k].x, rv[k].x, sad);
-                sad = __builtin_amdgcn_sad_u8(cur[k].y, rv[k].y, sad);
-                sad = __builtin_amdgcn_sad_u8(cur[k].z, rv[k].z, sad);
-                sad = __builtin_amdgcn_sad_u8(cur[k].w, rv[k].w, sad);
-            }
-        }
-        sad = wave_sum_u32(sad);
-        if ((threadIdx.x & 63) == 0) red[t & 1][threadIdx.x >> 6] = sad;
-        __syncthreads();
-        // every lane evaluates the (cheap, uniform) decision chain
-        const u32 tot = red[t & 1][0] + red[t & 1][1] + red[t & 1][2] + red[t & 1][3];
-        bool changed = true;
-        if (st.has_ref) {
-            const double mean_diff = (double)tot / (double)n;
-            changed = mean_diff > sp.change_threshold;
-        }
-        const bool should_process = !st.has_cache || changed;
-        // change_detector.py:137-150: pct = (changed / total) * 100 as a Python float
-        const double pct = sp.with_model ? ((double)sst.z_count / (double)sst.n) * 100.0 : 0.0;
-        const bool in_changes = sp.with_model && !(pct < 5.0);
-        // detect_piece on the current square, only where one of the two detectors asks for it
-        const bool fresh = (should_process || in_changes) ? d_detect_piece(sst) : false;
-        bool raw;
-        if (should_process) {
-            raw = fresh;
-            st.cached_raw = raw;
-            st.has_cache = 1;
-        } else {
-            raw = st.cached_raw != 0;
-        }
-        // _update_history / _get_stable_detection
-        st.hist_bits = (st.hist_bits << 1) | (raw ? 1u : 0u);
-        if ((int)st.hist_len < sp.history_size) st.hist_len++;
-        st.hist_bits &= (1u << st.hist_len) - 1u;
-        bool stable;
-        if (st.hist_len < 3) stable = raw;
-        else {
-            const double presence = (double)__popc(st.hist_bits) / (double)st.hist_len;
-            stable = presence >= sp.min_presence;
-        }
-        if (should_process && (raw == stable)) {
-#pragma unroll
-            for (int k = 0; k < SCAN_VPT; k++) rv[k] = cur[k];
-            st.has_ref = 1;
-        }
-        if (threadIdx.x == 0) {
-            cbv_frame_result* r = &results[t];
-            const u64 bit = 1ull << sq;
-            if (raw) atomicOr((unsigned long long*)&r->raw_occupied, bit);
-            if (stable) atomicOr((unsigned long long*)&r->stable_occupied, bit);
-            if (changed) atomicOr((unsigned long long*)&r->visual_changes, bit);
-            if (should_process) atomicOr((unsigned long long*)&r->processed, bit);
-            if (in_changes) {
-                atomicOr((unsigned long long*)&r->changed, bit);
-                if (pct > 75.0) atomicOr((unsigned long long*)&r->total, bit);
-                else if (pct > 15.0) atomicOr((unsigned long long*)&r->parcial, bit);
-                if (fresh) atomicOr((unsigned long long*)&r->circular, bit);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < SCAN_VPT; k++) cur[k] = nxt[k];
-        sst = nst;
     }
     if (st.has_ref) {
         uint4* refw = (uint4*)(ref + d.plane_off);
 #pragma unroll
-        for (int k = 0; k < SCAN_VPT; k++) {
-            const int vi = threadIdx.x + k * 256;
+        for (int k = 0; k < VPT; k++) {
+            const int vi = threadIdx.x + k * 64;
             if (vi < nvec) refw[vi] = rv[k];
         }
     }
     if (threadIdx.x == 0) state[sq] = st;
 }
 
+__global__ __launch_bounds__(64) void k_scan(const SquareDesc* __restrict__ descs, ScanParams sp,
+                                               const u8* __restrict__ gray, size_t gray_frame_stride,
+                                               const u8* __restrict__ decisions, u8* __restrict__ ref,
+                                               ScanState* __restrict__ state, u8* __restrict__ flags, int count)
+{
+    const SquareDesc d = descs[blockIdx.x];
+    const int nvec = (d.w * d.h + 15) >> 4;
+    // squares up to 90 x 90 px: eight 16-byte vectors per lane, planes fetched 4 frames ahead (the chain is
+    // latency-bound); up to 128 x 128: sixteen vectors, 2 frames ahead
+    if (nvec <= 512) scan_body<8, 4>(d, sp, gray, gray_frame_stride, decisions, ref, state, flags, count);
+    else scan_body<16, 2>(d, sp, gray, gray_frame_stride, decisions, ref, state, flags, count);
+}
+
+// per-square flag bytes of a frame -> the eight 64-bit square sets of cbv_frame_result
+__global__ void k_pack_results(const u8* __restrict__ flags, int n, cbv_frame_result* __restrict__ results, int count)
+{
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), sq = threadIdx.x & 63;
+    if (t >= count) return;
+    const u32 fl = sq < n ? flags[(size_t)t * CBV_MAX_SQUARES + sq] : 0u;
+    u64* r = (u64*)&results[t];
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        const u64 m = __ballot((fl >> b) & 1u);
+        if (sq == 0) r[b] = m;
+    }
+}
+
 int launch_scan(cbv_ctx* ctx, const SquareDesc* descs, ScanParams sp, const u8* gray, size_t gray_frame_stride,
-                const cbv_sq_stats* stats, u8* ref, ScanState* state, cbv_frame_result* results, int count)
+                const u8* decisions, u8* ref, ScanState* state, u8* flags, cbv_frame_result* results, int count)
 {
     prof_begin(ctx, CBV_K_SCAN);
-    hipLaunchKernelGGL(k_scan, dim3(sp.n), dim3(256), 0, ctx->stream, descs, sp, gray, gray_frame_stride, stats, ref, state,
-                       results, count);
+    hipLaunchKernelGGL(k_scan, dim3(sp.n), dim3(64), 0, ctx->stream, descs, sp, gray, gray_frame_stride, decisions, ref,
+                       state, flags, count);
+    hipLaunchKernelGGL(k_pack_results, dim3((count + 3) / 4), dim3(256), 0, ctx->stream, flags, sp.n, results, count);
     prof_end(ctx, CBV_K_SCAN);
     CBV_HIP(ctx, hipGetLastError());
     return CBV_OK;
