@@ -91,6 +91,16 @@ class FrameResult(C.Structure):
                 ("circular", C.c_uint64)]
 
 
+class NoiseResult(C.Structure):
+    _fields_ = [("state", C.c_uint8), ("msg", C.c_uint8), ("stable", C.c_uint8), ("lifted", C.c_int8),
+                ("count", C.c_uint16), ("blocked", C.c_uint16), ("squares", C.c_uint64)]
+
+
+class NoiseDevState(C.Structure):
+    _fields_ = [("state", C.c_uint32), ("stable_count", C.c_uint32), ("cooldown_count", C.c_uint32),
+                ("lifted", C.c_int32), ("pending", C.c_uint64)]
+
+
 KERNEL_IDS = ["COLOR_LAB_HIST", "CLAHE_LUT", "CLAHE_APPLY", "BILATERAL", "SHARPEN", "NORM_LUT", "NORMALIZE", "WARP",
               "SQUARES", "GRAY_BLUR", "OTSU", "THRESHOLD", "SCAN", "SYNTH", "RESET"]
 K = {name: i for i, name in enumerate(KERNEL_IDS)}
@@ -155,6 +165,8 @@ def load():
         "cbv_pipeline_run": (i32, [vp, i32, i32]),
         "cbv_pipeline_results": (i32, [vp, i32, i32, P(FrameResult)]),
         "cbv_pipeline_download": (i32, [vp, i32, i32, u8p]),
+        "cbv_pipeline_noise_results": (i32, [vp, i32, i32, P(NoiseResult)]),
+        "cbv_noise_run": (i32, [vp, vp, i32, P(NoiseDevState), P(NoiseResult)]),
         "cbv_pipeline_square_stats": (i32, [vp, i32, P(SqStats)]),
     }
     for name, (res, args) in proto.items():

@@ -818,7 +818,7 @@ struct cbv_pipeline {
     u8* enhanced = nullptr; // [max_frames] when keep_enhanced
     u8* warped = nullptr;   // [max_frames][S][S][3]
     size_t warped_stride = 0;
-    DevBuf d_descs, d_masks, d_gray, d_stats, d_ref, d_state, d_results, d_flags, d_dec, d_coef, d_synth, d_mean, d_var;
+    DevBuf d_descs, d_masks, d_gray, d_stats, d_ref, d_state, d_results, d_flags, d_dec, d_coef, d_synth, d_mean, d_var, d_noise, d_noise_state;
     bool calibrated = false;
     std::vector<SquareDesc> descs;
     size_t plane_total = 0;
@@ -861,7 +861,7 @@ extern "C" void cbv_pipeline_destroy(cbv_pipeline* p)
     if (p->frames) (void)hipFree(p->frames);
     if (p->enhanced) (void)hipFree(p->enhanced);
     if (p->warped) (void)hipFree(p->warped);
-    DevBuf* bufs[] = {&p->d_descs, &p->d_masks, &p->d_gray, &p->d_stats, &p->d_ref, &p->d_state, &p->d_results, &p->d_flags, &p->d_dec, &p->d_coef, &p->d_synth, &p->d_mean, &p->d_var};
+    DevBuf* bufs[] = {&p->d_descs, &p->d_masks, &p->d_gray, &p->d_stats, &p->d_ref, &p->d_state, &p->d_results, &p->d_flags, &p->d_dec, &p->d_noise, &p->d_noise_state, &p->d_coef, &p->d_synth, &p->d_mean, &p->d_var};
     for (auto b : bufs) dev_free(b);
     delete p;
 }
@@ -944,6 +944,9 @@ extern "C" int cbv_pipeline_configure(cbv_pipeline* p, const cbv_pipeline_config
     RC(dev_ensure(ctx, &p->d_results, sizeof(cbv_frame_result) * p->max_frames));
     RC(dev_ensure(ctx, &p->d_flags, (size_t)CBV_MAX_SQUARES * p->max_frames));
     RC(dev_ensure(ctx, &p->d_dec, (size_t)CBV_MAX_SQUARES * p->max_frames));
+    RC(dev_ensure(ctx, &p->d_noise, sizeof(cbv_noise_result) * p->max_frames));
+    RC(dev_ensure(ctx, &p->d_noise_state, sizeof(cbv_noise_state)));
+    CBV_HIP(ctx, hipMemset(p->d_noise_state.p, 0, sizeof(cbv_noise_state)));
     int coef[32] = {0};
     build_gaussian_q8(5, coef);
     RC(dev_ensure(ctx, &p->d_coef, sizeof(coef)));
@@ -964,6 +967,7 @@ extern "C" int cbv_pipeline_reset_state(cbv_pipeline* p)
     cbv_ctx* ctx = p->ctx;
     CBV_HIP(ctx, hipSetDevice(ctx->device));
     CBV_HIP(ctx, hipMemsetAsync(p->d_state.p, 0, sizeof(ScanState) * p->cfg.n_rois, ctx->stream));
+    CBV_HIP(ctx, hipMemsetAsync(p->d_noise_state.p, 0, sizeof(cbv_noise_state), ctx->stream));
     return CBV_OK;
 }
 
@@ -1079,6 +1083,9 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
     RC(launch_scan(ctx, (const SquareDesc*)p->d_descs.p, sp, (const u8*)p->d_gray.p + p->plane_total * slot0, p->plane_total,
                    (const u8*)p->d_dec.p + (size_t)CBV_MAX_SQUARES * slot0, (u8*)p->d_ref.p, (ScanState*)p->d_state.p,
                    (u8*)p->d_flags.p + (size_t)CBV_MAX_SQUARES * slot0, (cbv_frame_result*)p->d_results.p + slot0, count));
+    // NoiseHandler on the frames' visual_changes sets (game_session.py:165)
+    RC(launch_noise(ctx, &((const cbv_frame_result*)p->d_results.p + slot0)->visual_changes, sizeof(cbv_frame_result) / 8, count,
+                    (cbv_noise_state*)p->d_noise_state.p, (cbv_noise_result*)p->d_noise.p + slot0));
     return CBV_OK;
 }
 
@@ -1088,6 +1095,32 @@ extern "C" int cbv_pipeline_results(cbv_pipeline* p, int slot0, int count, cbv_f
     cbv_ctx* ctx = p->ctx;
     CBV_HIP(ctx, hipSetDevice(ctx->device));
     CBV_HIP(ctx, hipMemcpyAsync(out, (cbv_frame_result*)p->d_results.p + slot0, sizeof(cbv_frame_result) * count, hipMemcpyDeviceToHost, ctx->stream));
+    CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CBV_OK;
+}
+
+extern "C" int cbv_pipeline_noise_results(cbv_pipeline* p, int slot0, int count, cbv_noise_result* out)
+{
+    if (!p || !out || !p->configured || slot0 < 0 || count <= 0 || slot0 + count > p->max_frames) return CBV_ERR_ARG;
+    cbv_ctx* ctx = p->ctx;
+    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_HIP(ctx, hipMemcpyAsync(out, (cbv_noise_result*)p->d_noise.p + slot0, sizeof(cbv_noise_result) * count, hipMemcpyDeviceToHost, ctx->stream));
+    CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CBV_OK;
+}
+
+extern "C" int cbv_noise_run(cbv_ctx* ctx, const uint64_t* changes, int n, cbv_noise_state* state, cbv_noise_result* out)
+{
+    if (!ctx || !changes || !state || !out || n <= 0) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_noise_run: bad arguments");
+    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    size_t b_in = ((size_t)n * 8 + 255) & ~(size_t)255, b_out = ((size_t)n * sizeof(cbv_noise_result) + 255) & ~(size_t)255;
+    RC(dev_ensure(ctx, &ctx->c, b_in + b_out + 256));
+    u8* base = (u8*)ctx->c.p;
+    CBV_HIP(ctx, hipMemcpyAsync(base, changes, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    CBV_HIP(ctx, hipMemcpyAsync(base + b_in + b_out, state, sizeof(cbv_noise_state), hipMemcpyHostToDevice, ctx->stream));
+    RC(launch_noise(ctx, (const u64*)base, 1, n, (cbv_noise_state*)(base + b_in + b_out), (cbv_noise_result*)(base + b_in)));
+    CBV_HIP(ctx, hipMemcpyAsync(out, base + b_in, (size_t)n * sizeof(cbv_noise_result), hipMemcpyDeviceToHost, ctx->stream));
+    CBV_HIP(ctx, hipMemcpyAsync(state, base + b_in + b_out, sizeof(cbv_noise_state), hipMemcpyDeviceToHost, ctx->stream));
     CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return CBV_OK;
 }

@@ -449,6 +449,78 @@ __global__ void k_pack_results(const u8* __restrict__ flags, int n, cbv_frame_re
     }
 }
 
+// ---------------------------------------------------------------------------
+// NoiseHandler.process (noise_handler.py:49-213): a 3-state machine over the per-frame set of
+// visually changed squares.  Sequential and tiny: one lane walks the frames.
+// ---------------------------------------------------------------------------
+__global__ void k_noise(const u64* __restrict__ changes, size_t stride_words, int count, cbv_noise_state* __restrict__ state,
+                        cbv_noise_result* __restrict__ out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int NOISE_THRESHOLD = 3, STABILITY_FRAMES = 12, COOLDOWN_FRAMES = 5;
+    cbv_noise_state s = *state;
+    for (int t = 0; t < count; t++) {
+        const u64 ch = changes[(size_t)t * stride_words];
+        const int n = __popcll(ch);
+        const bool noisy = n > NOISE_THRESHOLD;
+        const int single = n == 1 ? (int)__ffsll((long long)ch) - 1 : -1;
+        cbv_noise_result r;
+        r.state = 0; r.msg = 0; r.stable = 0; r.lifted = -1; r.count = 0; r.blocked = 0; r.squares = 0;
+        if (s.state == 0) { // IDLE
+            if (n == 0) { r.state = 0; r.msg = 0; }
+            else if (noisy) { s.state = 1; s.cooldown_count = 0; r.state = 1; r.msg = 1; r.count = (u16)n; }
+            else {
+                s.state = 2; s.pending = ch; s.stable_count = 1; s.lifted = single + 1;
+                r.state = 2; r.msg = 2; r.squares = ch; r.lifted = (signed char)single; r.count = 1;
+            }
+        } else if (s.state == 1) { // NOISE_ACTIVE
+            if (noisy) { s.cooldown_count = 0; r.state = 1; r.msg = 6; r.count = (u16)n; }
+            else {
+                s.cooldown_count++;
+                const bool done = (int)s.cooldown_count >= COOLDOWN_FRAMES;
+                if (n == 0) {
+                    if (done) { s.state = 0; s.cooldown_count = 0; r.state = 0; r.msg = 3; }
+                    else { r.state = 1; r.msg = 4; r.count = (u16)s.cooldown_count; }
+                } else if (done) {
+                    s.state = 2; s.pending = ch; s.stable_count = 1;
+                    r.state = 2; r.msg = 7; r.squares = ch;
+                } else { r.state = 1; r.msg = 5; r.count = (u16)n; }
+            }
+        } else { // MOVE_PENDING
+            if (noisy) {
+                s.state = 1; s.pending = 0; s.stable_count = 0; s.cooldown_count = 0;
+                r.state = 1; r.msg = 8; r.count = (u16)n;
+            } else if (n == 0) {
+                s.stable_count++;
+                if ((int)s.stable_count >= STABILITY_FRAMES) {
+                    r.state = 0; r.msg = 9; r.squares = s.pending; r.stable = 1;
+                    s.state = 0; s.pending = 0; s.stable_count = 0; s.cooldown_count = 0; s.lifted = 0;
+                } else { r.state = 2; r.msg = 10; r.squares = s.pending; r.count = (u16)s.stable_count; }
+            } else if (ch == s.pending) {
+                s.stable_count++;
+                if ((int)s.stable_count >= STABILITY_FRAMES) { r.state = 2; r.msg = 11; r.squares = s.pending; r.stable = 1; }
+                else {
+                    r.state = 2; r.msg = 12; r.squares = s.pending; r.count = (u16)s.stable_count;
+                    r.lifted = (signed char)(__popcll(s.pending) == 1 ? s.lifted - 1 : -1);
+                }
+            } else {
+                s.pending = ch; s.stable_count = 1; s.lifted = single + 1;
+                r.state = 2; r.msg = 13; r.squares = ch; r.lifted = (signed char)single; r.count = 1;
+            }
+        }
+        r.blocked = s.state == 1 ? 1 : 0;
+        out[t] = r;
+    }
+    *state = s;
+}
+
+int launch_noise(cbv_ctx* ctx, const u64* changes, size_t stride_words, int count, cbv_noise_state* state, cbv_noise_result* out)
+{
+    hipLaunchKernelGGL(k_noise, dim3(1), dim3(64), 0, ctx->stream, changes, stride_words, count, state, out);
+    CBV_HIP(ctx, hipGetLastError());
+    return CBV_OK;
+}
+
 int launch_scan(cbv_ctx* ctx, const SquareDesc* descs, ScanParams sp, const u8* gray, size_t gray_frame_stride,
                 const u8* decisions, u8* ref, ScanState* state, u8* flags, cbv_frame_result* results, int count)
 {

@@ -128,6 +128,14 @@ class BoardPipeline:
         self.ctx.check(self.ctx.lib.cbv_pipeline_results(self.h_, slot0, count, out))
         return out
 
+    def noise_results(self, slot0, count):
+        """NoiseHandler.process outputs of the frames, as (NoiseState, data) tuples (game_session.py:165)."""
+        from .noise_handler import decode_device_result
+        out = (N.NoiseResult * count)()
+        self.ctx.check(self.ctx.lib.cbv_pipeline_noise_results(self.h_, slot0, count, out))
+        idx2pos = [(c, 7 - r) for (r, c) in self.rois_rc]
+        return [decode_device_result(r, idx2pos) for r in out]
+
     def download(self, which, slot):
         shape = (self.h, self.w, 3) if which in (0, 1) else (self.board_size, self.board_size, 3)
         out = np.empty(shape, np.uint8)

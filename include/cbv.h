@@ -232,6 +232,33 @@ typedef struct {
     uint64_t circular;         /* detect_piece(current square)['has_piece'], evaluated fresh */
 } cbv_frame_result;
 
+/* NoiseHandler.process (noise_handler.py:49-213) evaluated on the device for every frame from its
+ * visual_changes set.  `msg` selects the shape of the reference's data dict:
+ *  0 waiting            1 hand_detected {changed_count}    2 detecting (from IDLE) {squares, lifted, stable, progress}
+ *  3 noise_cleared      4 clearing {cooldown, progress}     5 stabilizing (NOISE) {changed_count}
+ *  6 hand_active {changed_count}   7 detecting (from NOISE) {squares, stable}   8 interrupted_by_hand {changed_count}
+ *  9 move_ready {squares, stable}  10 stabilizing (PENDING) {squares, stable, progress}
+ * 11 stable_ready {squares, stable, progress}  12 counting {squares, lifted, stable, progress}  13 updated {...} */
+typedef struct {
+    uint8_t state;    /* returned state: 0 IDLE, 1 NOISE_ACTIVE, 2 MOVE_PENDING */
+    uint8_t msg;
+    uint8_t stable;   /* data["stable"] */
+    int8_t lifted;    /* roi index of data["lifted"], -1 = None */
+    uint16_t count;   /* changed_count, cooldown or stable_count (progress = count / 5 or / 12), by msg */
+    uint16_t blocked; /* is_blocked() after the frame */
+    uint64_t squares; /* data["squares"] */
+} cbv_noise_result;
+
+typedef struct {
+    uint32_t state, stable_count, cooldown_count;
+    int32_t lifted;   /* roi index + 1 of last_lifted_square, 0 = None */
+    uint64_t pending;
+} cbv_noise_state;
+
+/* Run the state machine over `n` change sets (bit i = roi i); `state` is read and updated
+ * (zero-initialised = a fresh NoiseHandler).  Host buffers. */
+CBV_API int cbv_noise_run(cbv_ctx* ctx, const uint64_t* changes, int n, cbv_noise_state* state, cbv_noise_result* out);
+
 CBV_API int cbv_pipeline_create(cbv_ctx* ctx, int w, int h, int max_frames, cbv_pipeline** out);
 CBV_API void cbv_pipeline_destroy(cbv_pipeline* p);
 CBV_API int cbv_pipeline_configure(cbv_pipeline* p, const cbv_pipeline_config* cfg);
@@ -249,6 +276,8 @@ CBV_API int cbv_pipeline_calibrate(cbv_pipeline* p, int slot);
 /* enqueue enhance -> warp -> detect for frames [slot0, slot0+count) in stream order; asynchronous */
 CBV_API int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count);
 CBV_API int cbv_pipeline_results(cbv_pipeline* p, int slot0, int count, cbv_frame_result* out);
+/* NoiseHandler outputs of the same frames (fed by their visual_changes, like game_session.py:165) */
+CBV_API int cbv_pipeline_noise_results(cbv_pipeline* p, int slot0, int count, cbv_noise_result* out);
 /* download intermediates of one slot for parity checks: which = 0 input, 1 enhanced, 2 warped */
 CBV_API int cbv_pipeline_download(cbv_pipeline* p, int which, int slot, uint8_t* out);
 CBV_API int cbv_pipeline_square_stats(cbv_pipeline* p, int slot, cbv_sq_stats* out /* n_rois */);

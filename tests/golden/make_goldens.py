@@ -11,7 +11,8 @@ What is and is not exercised:
     _update_history/_get_stable_detection, split_board, reorder,
     classify_hand_pattern).  cv2 stays functionally absent: any call into it
     would raise AttributeError.  No OpenCV arithmetic is pinned by these files.
-  * noise_handler.py imports cleanly (no third-party deps).
+  * noise_handler.py imports cleanly (no third-party deps): state/data per frame for scripted and random
+    change sequences.
 
 Run:  python tests/golden/make_goldens.py   (needs /root/reference)
 """
@@ -185,7 +186,62 @@ def gold_hand_pattern():
         json.dump(cases, f)
 
 
+def gold_noise():
+    """noise_handler.py imports cleanly; sequences chosen to walk every transition, plus random ones."""
+    import noise_handler
+    def norm(state, data):
+        d = {}
+        for k, v in data.items():
+            if isinstance(v, set):
+                d[k] = sorted(list(x) for x in v)
+            elif isinstance(v, tuple):
+                d[k] = list(v)
+            else:
+                d[k] = v
+        return {"state": state.name, "data": d}
+    A, B, C, D, E = (4, 1), (4, 3), (0, 0), (7, 7), (2, 5)
+    hand = {(0, 0), (1, 0), (2, 0), (3, 0), (4, 0)}
+    scripted = [
+        [set()] * 3 + [{A}] * 13 + [set()] * 2,                                    # lift, counting -> stable_ready
+        [{A, B}] + [set()] * 12 + [set()],                                         # detecting -> stabilizing -> move_ready
+        [hand] + [set()] * 5 + [set()],                                            # hand -> clearing -> noise_cleared
+        [hand, {A}, {A}, {A}, {A}, {A}, {A}] + [{A}] * 12,                         # hand -> stabilizing -> detecting -> counting
+        [{A}, {A, B}, {A, B}, hand, hand, {C}, hand, set(), set(), set(), set(), set(), {D, E, A}],  # updated, interrupted, hand_active
+        [{A, B, C}, {A, B, C}, {A, B}, {A}, set(), {A}],
+    ]
+    out = []
+    for seq in scripted:
+        h = noise_handler.NoiseHandler()
+        steps = []
+        for ch in seq:
+            st, data = h.process(set(ch))
+            steps.append({"changed": sorted(list(x) for x in ch), **norm(st, data), "blocked": h.is_blocked(), "name": h.get_state_name()})
+        out.append(steps)
+    rng = np.random.default_rng(77)
+    squares = [(f, r) for f in range(8) for r in range(8)]
+    for _ in range(12):
+        h = noise_handler.NoiseHandler()
+        steps = []
+        cur = set()
+        for _ in range(160):
+            u = rng.random()
+            if u < 0.55:
+                pass  # keep the same set: lets counters run
+            elif u < 0.75:
+                cur = set()
+            elif u < 0.92:
+                cur = {squares[i] for i in rng.choice(64, size=rng.integers(1, 4), replace=False)}
+            else:
+                cur = {squares[i] for i in rng.choice(64, size=rng.integers(4, 12), replace=False)}
+            st, data = h.process(set(cur))
+            steps.append({"changed": sorted(list(x) for x in cur), **norm(st, data), "blocked": h.is_blocked(), "name": h.get_state_name()})
+        out.append(steps)
+    with open(os.path.join(OUT, "noise_handler.json"), "w") as f:
+        json.dump(out, f)
+
+
 if __name__ == "__main__":
+    gold_noise()
     gold_fen()
     gold_piece_numpy()
     gold_grid()

@@ -130,3 +130,31 @@ def test_piece_masks_and_sums_match_reference_numpy():
         assert res["has_piece"] == exp_has, i
         if np.std(g) >= 15:
             assert res["center_border_diff"] == cvb[i][0]
+
+
+def _norm_noise(state, data):
+    d = {}
+    for k, v in data.items():
+        d[k] = sorted(list(x) for x in v) if isinstance(v, set) else (list(v) if isinstance(v, tuple) else v)
+    return state.name, d
+
+
+def test_noise_handler_goldens():
+    """Every (state, data) the reference's NoiseHandler returns over scripted and random change
+    sequences (tests/golden/noise_handler.json) is reproduced by the drop-in class."""
+    from chessboard_vision_amd.noise_handler import NoiseHandler, NoiseState
+    seqs = jload("noise_handler.json")
+    seen = set()
+    for steps in seqs:
+        h = NoiseHandler()
+        assert h.state == NoiseState.IDLE and not h.is_blocked()
+        for i, st in enumerate(steps):
+            state, data = h.process({tuple(x) for x in st["changed"]})
+            name, d = _norm_noise(state, data)
+            assert name == st["state"] and d == st["data"], (i, name, d, st)
+            assert h.is_blocked() == st["blocked"] and h.get_state_name() == st["name"]
+            seen.add(d.get("message"))
+    from chessboard_vision_amd.noise_handler import MESSAGES
+    assert seen == set(MESSAGES)  # every transition of the machine is covered by the goldens
+    h.reset()
+    assert h.state == NoiseState.IDLE and h.stable_count == 0 and len(h.pending_squares) == 0

@@ -193,3 +193,39 @@ def test_pipeline_change_detector_stage(gpu_ctx, oracle):
         assert got == exp, (i, got, exp)
         seen |= {v["intensity"] for v in exp.values()}
     assert "TOTAL" in seen or "PARCIAL" in seen  # the scripted moves do change squares
+
+
+def test_noise_handler_device_matches_reference_goldens(gpu_ctx):
+    """cbv_noise_run (the k_noise kernel) against every step of the reference NoiseHandler's
+    recorded sequences (tests/golden/noise_handler.json)."""
+    import json
+    import os
+    from chessboard_vision_amd.noise_handler import run_on_device
+    seqs = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "noise_handler.json")))
+    pos_to_index = {(f, r): (7 - r) * 8 + f for f in range(8) for r in range(8)}
+    for steps in seqs:
+        sets = [{tuple(x) for x in st["changed"]} for st in steps]
+        got, _ = run_on_device(sets, pos_to_index)
+        for i, ((state, data), st) in enumerate(zip(got, steps)):
+            d = {k: (sorted(list(x) for x in v) if isinstance(v, set) else (list(v) if isinstance(v, tuple) else v)) for k, v in data.items()}
+            assert state.name == st["state"] and d == st["data"], (i, state, d, st)
+
+
+def test_pipeline_noise_stage_matches_host_class(gpu_ctx):
+    """The pipeline's per-frame NoiseHandler outputs equal the host class fed with the same visual_changes."""
+    from chessboard_vision_amd.noise_handler import NoiseHandler
+    from chessboard_vision_amd.stream import BoardPipeline, bits_to_positions
+    n = 48
+    pts = S.scaled_corners(W, H)
+    p = BoardPipeline(W, H, n)
+    p.configure(pts, profile={}, chunk=16)
+    p.synth(0, n, scene="normal", frames_per_ply=14)
+    p.run(0, n)
+    res, noise = p.results(0, n), p.noise_results(0, n)
+    h = NoiseHandler()
+    states = set()
+    for i in range(n):
+        exp = h.process(bits_to_positions(res[i].visual_changes, p.rois_rc))
+        assert noise[i] == exp, (i, noise[i], exp)
+        states.add(exp[0].name)
+    assert {"NOISE_ACTIVE", "IDLE", "MOVE_PENDING"} <= states  # first frame = 64 changes (hand), then moves settle
