@@ -78,11 +78,27 @@ class Scene(C.Structure):
         return s
 
 
+class HoughParams(C.Structure):
+    _fields_ = [("dp", C.c_double), ("param1", C.c_double), ("param2", C.c_double), ("min_radius_ratio", C.c_double),
+                ("max_radius_ratio", C.c_double)]
+
+
+HOUGH_KEEP = 6
+HOUGH_OVERFLOW, HOUGH_SKIPPED = 1, 2
+
+
+class HoughResult(C.Structure):
+    _fields_ = [("found", C.c_uint8), ("kind", C.c_uint8), ("n_circles", C.c_uint16), ("cx", C.c_float), ("cy", C.c_float),
+                ("r", C.c_float), ("votes", C.c_int32), ("n_edges", C.c_uint32), ("n_centres", C.c_uint16),
+                ("flags", C.c_uint16), ("circles", (C.c_float * 4) * HOUGH_KEEP)]
+
+
 class PipelineConfig(C.Structure):
     _fields_ = [("enhance", EnhanceParams), ("M", C.c_double * 9), ("board_size", C.c_int32), ("rot180", C.c_int32),
                 ("n_rois", C.c_int32), ("rois", Roi * MAX_SQUARES), ("history_size", C.c_int32),
                 ("min_presence", C.c_double), ("change_threshold", C.c_double), ("chunk", C.c_int32),
-                ("lanes", C.c_int32), ("z_threshold", C.c_double), ("initial_variance", C.c_double), ("keep_enhanced", C.c_int32)]
+                ("lanes", C.c_int32), ("z_threshold", C.c_double), ("initial_variance", C.c_double), ("keep_enhanced", C.c_int32),
+                ("use_hough", C.c_int32), ("hough", HoughParams)]
 
 
 class FrameResult(C.Structure):
@@ -102,7 +118,7 @@ class NoiseDevState(C.Structure):
 
 
 KERNEL_IDS = ["COLOR_LAB_HIST", "CLAHE_LUT", "CLAHE_APPLY", "BILATERAL", "SHARPEN", "NORM_LUT", "NORMALIZE", "WARP",
-              "SQUARES", "GRAY_BLUR", "OTSU", "THRESHOLD", "SCAN", "SYNTH", "RESET"]
+              "SQUARES", "GRAY_BLUR", "OTSU", "THRESHOLD", "SCAN", "SYNTH", "RESET", "HOUGH"]
 K = {name: i for i, name in enumerate(KERNEL_IDS)}
 
 _lib = None
@@ -151,6 +167,7 @@ def load():
         "cbv_squares_ema": (i32, [vp, dbl, vp]),
         "cbv_squares_set_ref": (i32, [vp, vp]),
         "cbv_squares_stats": (i32, [vp, i32, i32, dbl, P(SqStats)]),
+        "cbv_squares_hough": (i32, [vp, P(HoughParams), P(HoughResult)]),
         "cbv_squares_get": (i32, [vp, i32, i32, vp]),
         "cbv_squares_set": (i32, [vp, i32, i32, vp]),
         "cbv_squares_geometry": (i32, [vp, i32, P(i32), P(i32)]),
@@ -168,6 +185,7 @@ def load():
         "cbv_pipeline_noise_results": (i32, [vp, i32, i32, P(NoiseResult)]),
         "cbv_noise_run": (i32, [vp, vp, i32, P(NoiseDevState), P(NoiseResult)]),
         "cbv_pipeline_square_stats": (i32, [vp, i32, P(SqStats)]),
+        "cbv_pipeline_hough": (i32, [vp, i32, P(HoughResult)]),
     }
     for name, (res, args) in proto.items():
         fn = getattr(lib, name)  # AttributeError here means the .so is stale

@@ -93,6 +93,13 @@ class SquareSet:
         self.ctx.check(self.ctx.lib.cbv_squares_stats(self.h, 1 if use_ref else 0, 1 if use_model else 0, float(z_threshold), out))
         return out
 
+    def hough(self, dp=1.2, param1=100, param2=25, min_radius_ratio=0.20, max_radius_ratio=0.55):
+        """_detect_circle_unified (piece_detector.py:210-270) for every loaded square."""
+        prm = N.HoughParams(float(dp), float(param1), float(param2), float(min_radius_ratio), float(max_radius_ratio))
+        out = (N.HoughResult * len(self.keys))()
+        self.ctx.check(self.ctx.lib.cbv_squares_hough(self.h, prm, out))
+        return out
+
     def get(self, which, pos):
         i = self.index[pos]
         h, w = self.shapes[i]

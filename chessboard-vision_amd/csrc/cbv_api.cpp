@@ -49,7 +49,7 @@ void dev_free(DevBuf* b)
 // ---------------------------------------------------------------------------
 static const char* kKernelNames[CBV_K_COUNT] = {
     "k_color_lab_hist", "k_clahe_lut", "k_clahe_apply", "k_bilateral", "k_sharpen", "k_norm_lut", "k_normalize",
-    "k_warp", "k_squares", "k_gray_blur_hist", "k_otsu", "k_threshold", "k_scan", "k_synth", "k_reset_aux"};
+    "k_warp", "k_squares", "k_gray_blur_hist", "k_otsu", "k_threshold", "k_scan", "k_synth", "k_reset_aux", "k_hough"};
 
 static hipEvent_t prof_get_event(cbv_ctx* ctx)
 {
@@ -516,7 +516,7 @@ struct cbv_squares {
     int blur_k = 0;
     std::vector<SquareDesc> descs;
     size_t plane_total = 0, mask_total = 0;
-    DevBuf d_descs, d_masks, d_gray, d_ref, d_mean, d_var, d_stats, d_select, d_coef, d_stage;
+    DevBuf d_descs, d_masks, d_gray, d_ref, d_mean, d_var, d_stats, d_select, d_coef, d_stage, d_hough;
     std::vector<u8> stage;
     bool has_ref = false, has_model = false;
     int coef_k = -1;
@@ -742,6 +742,38 @@ extern "C" int cbv_squares_stats(cbv_squares* s, int use_ref, int use_model, dou
     return CBV_OK;
 }
 
+static int hough_cfg(cbv_ctx* ctx, const cbv_hough_params* prm, const std::vector<SquareDesc>& descs, HoughCfg* hc)
+{
+    if (!prm || !(prm->dp > 0) || prm->param1 < 0 || prm->param2 < 0 || !(prm->max_radius_ratio >= 0) || !(prm->min_radius_ratio >= 0))
+        return cbv_fail(ctx, CBV_ERR_ARG, "HoughCircles parameters are invalid");
+    memset(hc, 0, sizeof(*hc));
+    hc->dp = (float)prm->dp < 1.f ? 1.f : (float)prm->dp;
+    hc->canny_thr = (int)nearbyint(prm->param1);
+    hc->acc_thr = (int)nearbyint(prm->param2);
+    hc->min_ratio = prm->min_radius_ratio;
+    hc->max_ratio = prm->max_radius_ratio;
+    for (const SquareDesc& d : descs) {
+        hc->maxw = std::max(hc->maxw, d.w);
+        hc->maxh = std::max(hc->maxh, d.h);
+    }
+    return CBV_OK;
+}
+
+extern "C" int cbv_squares_hough(cbv_squares* s, const cbv_hough_params* prm, cbv_hough_result* out)
+{
+    if (!s) return CBV_ERR_ARG;
+    cbv_ctx* ctx = s->ctx;
+    if (!out || s->n == 0) return cbv_fail(ctx, CBV_ERR_STATE, "cbv_squares_hough: no squares loaded or null output");
+    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    HoughCfg hc;
+    RC(hough_cfg(ctx, prm, s->descs, &hc));
+    RC(dev_ensure(ctx, &s->d_hough, sizeof(cbv_hough_result) * CBV_MAX_SQUARES));
+    RC(launch_hough(ctx, (const SquareDesc*)s->d_descs.p, s->n, (const u8*)s->d_gray.p, 0, hc, (cbv_hough_result*)s->d_hough.p, nullptr, 1));
+    CBV_HIP(ctx, hipMemcpyAsync(out, s->d_hough.p, sizeof(cbv_hough_result) * s->n, hipMemcpyDeviceToHost, ctx->stream));
+    CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CBV_OK;
+}
+
 static int squares_plane(cbv_squares* s, int which, int index, void** p, size_t* bytes)
 {
     cbv_ctx* ctx = s->ctx;
@@ -818,7 +850,8 @@ struct cbv_pipeline {
     u8* enhanced = nullptr; // [max_frames] when keep_enhanced
     u8* warped = nullptr;   // [max_frames][S][S][3]
     size_t warped_stride = 0;
-    DevBuf d_descs, d_masks, d_gray, d_stats, d_ref, d_state, d_results, d_flags, d_dec, d_coef, d_synth, d_mean, d_var, d_noise, d_noise_state;
+    DevBuf d_descs, d_masks, d_gray, d_stats, d_ref, d_state, d_results, d_flags, d_dec, d_coef, d_synth, d_mean, d_var, d_noise, d_noise_state, d_hough;
+    HoughCfg hough_cfg;
     bool calibrated = false;
     std::vector<SquareDesc> descs;
     size_t plane_total = 0;
@@ -944,6 +977,10 @@ extern "C" int cbv_pipeline_configure(cbv_pipeline* p, const cbv_pipeline_config
     RC(dev_ensure(ctx, &p->d_results, sizeof(cbv_frame_result) * p->max_frames));
     RC(dev_ensure(ctx, &p->d_flags, (size_t)CBV_MAX_SQUARES * p->max_frames));
     RC(dev_ensure(ctx, &p->d_dec, (size_t)CBV_MAX_SQUARES * p->max_frames));
+    if (cfg->use_hough) {
+        RC(hough_cfg(ctx, &cfg->hough, p->descs, &p->hough_cfg));
+        RC(dev_ensure(ctx, &p->d_hough, sizeof(cbv_hough_result) * CBV_MAX_SQUARES * p->max_frames));
+    }
     RC(dev_ensure(ctx, &p->d_noise, sizeof(cbv_noise_result) * p->max_frames));
     RC(dev_ensure(ctx, &p->d_noise_state, sizeof(cbv_noise_state)));
     CBV_HIP(ctx, hipMemset(p->d_noise_state.p, 0, sizeof(cbv_noise_state)));
@@ -1057,10 +1094,15 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
         rc_all = launch_squares_preprocess(ctx, wdst, p->warped_stride, (const SquareDesc*)p->d_descs.p, n, (const int*)p->d_coef.p, 5,
                                            (u8*)p->d_gray.p + p->plane_total * s0, p->plane_total, b);
         if (rc_all) break;
+        u8* dec = (u8*)p->d_dec.p + (size_t)CBV_MAX_SQUARES * s0;
         rc_all = launch_squares_stats(ctx, (const SquareDesc*)p->d_descs.p, n, (const u8*)p->d_gray.p + p->plane_total * s0, p->plane_total,
                                       nullptr, p->calibrated ? (const float*)p->d_mean.p : nullptr, p->calibrated ? (const float*)p->d_var.p : nullptr,
                                       (const u8*)p->d_masks.p, (float)cfg.z_threshold, (cbv_sq_stats*)p->d_stats.p + (size_t)n * s0, b,
-                                      (u8*)p->d_dec.p + (size_t)CBV_MAX_SQUARES * s0);
+                                      dec, cfg.use_hough);
+        if (rc_all) break;
+        if (cfg.use_hough)
+            rc_all = launch_hough(ctx, (const SquareDesc*)p->d_descs.p, n, (const u8*)p->d_gray.p + p->plane_total * s0, p->plane_total,
+                                  p->hough_cfg, (cbv_hough_result*)p->d_hough.p + (size_t)CBV_MAX_SQUARES * s0, dec, b);
     }
     ctx->stream = main_stream;
     if (rc_all) return rc_all;
@@ -1146,6 +1188,18 @@ extern "C" int cbv_pipeline_download(cbv_pipeline* p, int which, int slot, uint8
     } else
         return cbv_fail(ctx, CBV_ERR_ARG, "bad buffer selector %d", which);
     CBV_HIP(ctx, hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CBV_OK;
+}
+
+extern "C" int cbv_pipeline_hough(cbv_pipeline* p, int slot, cbv_hough_result* out)
+{
+    if (!p || !out || slot < 0 || slot >= p->max_frames) return CBV_ERR_ARG;
+    cbv_ctx* ctx = p->ctx;
+    if (!p->configured || !p->cfg.use_hough) return cbv_fail(ctx, CBV_ERR_STATE, "cbv_pipeline_hough: the HoughCircles stage is not configured");
+    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_HIP(ctx, hipMemcpyAsync(out, (const cbv_hough_result*)p->d_hough.p + (size_t)CBV_MAX_SQUARES * slot,
+                                sizeof(cbv_hough_result) * CBV_MAX_SQUARES, hipMemcpyDeviceToHost, ctx->stream));
     CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return CBV_OK;
 }

@@ -187,7 +187,19 @@ int launch_squares_preprocess(cbv_ctx* ctx, const u8* src, size_t src_frame_stri
                               const int* coef_dev, int blur_k, u8* gray, size_t gray_frame_stride, int batch);
 int launch_squares_stats(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, size_t gray_frame_stride,
                          const u8* ref, const float* mean, const float* var, const u8* masks, float z_thresh,
-                         cbv_sq_stats* out, int batch, u8* decisions = nullptr);
+                         cbv_sq_stats* out, int batch, u8* decisions = nullptr, int want_hough = 0);
+
+// HoughCircles per square (k_hough.hip).  off_* / max_* are filled by launch_hough.
+struct HoughCfg {
+    float dp;
+    int canny_thr, acc_thr;
+    double min_ratio, max_ratio;
+    int maxw, maxh; // largest square of the set
+    int off_map, off_mag, off_acc, off_centres, off_bins, off_order, max_bins;
+};
+// `decisions` (may be null): squares whose byte lacks bit 4 are skipped; a found circle sets bit 0.
+int launch_hough(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, size_t gray_frame_stride, HoughCfg cfg,
+                 cbv_hough_result* out, u8* decisions, int batch);
 int launch_squares_calibrate(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, float* mean, float* var,
                              float init_var, const u8* select);
 int launch_squares_ema(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, float* mean, float* var,

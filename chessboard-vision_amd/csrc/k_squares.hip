@@ -114,21 +114,24 @@ int launch_squares_preprocess(cbv_ctx* ctx, const u8* src, size_t src_frame_stri
 // PieceDetector.detect_piece decision chain without HoughCircles
 // (piece_detector.py:303-345), evaluated in double like numpy does.
 // ---------------------------------------------------------------------------
-__device__ bool d_detect_piece(const cbv_sq_stats& st)
+// detect_piece without its HoughCircles step (piece_detector.py:303-345):
+// 0 = uniform square (std < 15: no piece, nothing else is tried), 1 = centre-vs-border or radial symmetry says
+// piece, 2 = neither does (only then the outcome of HoughCircles decides `has_piece`).
+__device__ int d_detect_piece(const cbv_sq_stats& st)
 {
     // np.std(gray) < 15  <=>  n*sumsq - sum^2 < 225 n^2   (exact integer form)
     const long long n = st.n, s = st.sum;
     const long long lhs = n * (long long)st.sumsq - s * s;
-    if (lhs < 225ll * n * n) return false;
+    if (lhs < 225ll * n * n) return 0;
     const double cm = (double)st.center_sum / (double)st.center_cnt;
     const double bm = (double)st.border_sum / (double)st.border_cnt;
     const double diff = fabs(cm - bm);
-    if (diff > 40.0) return true;
+    if (diff > 40.0) return 1;
     double rm[4];
     int nr = 0;
     for (int k = 0; k < 4; k++)
         if (st.ring_cnt[k] > 0) rm[nr++] = (double)st.ring_sum[k] / (double)st.ring_cnt[k];
-    if (nr < 2) return false;
+    if (nr < 2) return 2;
     double sum = 0;
     for (int k = 0; k < nr; k++) sum = sum + rm[k];
     const double mean = sum / nr;
@@ -139,7 +142,7 @@ __device__ bool d_detect_piece(const cbv_sq_stats& st)
     }
     const double variance = sq / nr;
     const double score = fmin(1.0, variance / 500.0);
-    return score > 0.6;
+    return score > 0.6 ? 1 : 2;
 }
 
 // ---------------------------------------------------------------------------
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(256) void k_squares_stats(const SquareDesc* __restr
                                                         const u8* __restrict__ ref, const float* __restrict__ mean,
                                                         const float* __restrict__ var, const u8* __restrict__ masks,
                                                         float z_thresh, cbv_sq_stats* __restrict__ out, int nsq,
-                                                        u8* __restrict__ decisions)
+                                                        u8* __restrict__ decisions, int want_hough)
 {
     __shared__ u32 acc[20];
     __shared__ float zm[4];
@@ -219,8 +222,12 @@ __global__ __launch_bounds__(256) void k_squares_stats(const SquareDesc* __restr
         out[(size_t)blockIdx.z * nsq + blockIdx.x] = st;
         if (decisions) {
             // the frame-parallel part of both detectors' decisions, so the sequential scan only does integer work:
-            // bit0 detect_piece(square), bits 1-3 ChangeDetector class (in dict / PARCIAL / TOTAL)
-            u32 dc = d_detect_piece(st) ? 1u : 0u;
+            // bit0 detect_piece(square), bits 1-3 ChangeDetector class (in dict / PARCIAL / TOTAL),
+            // bit4 "HoughCircles decides": has_piece is an OR, so k_hough only has to run where the two
+            // statistics-based detectors said no on a non-uniform square; it then sets bit0 itself
+            const int dp = d_detect_piece(st);
+            u32 dc = dp == 1 ? 1u : 0u;
+            if (want_hough && (dp == 2 || (want_hough == 2 && dp == 1))) dc |= 16u;
             if (mean) {
                 const double pct = ((double)st.z_count / (double)st.n) * 100.0; // change_detector.py:139 as a Python float
                 if (!(pct < 5.0)) dc |= 2u | (pct > 75.0 ? 8u : (pct > 15.0 ? 4u : 0u));
@@ -232,11 +239,11 @@ __global__ __launch_bounds__(256) void k_squares_stats(const SquareDesc* __restr
 
 int launch_squares_stats(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, size_t gray_frame_stride,
                          const u8* ref, const float* mean, const float* var, const u8* masks, float z_thresh,
-                         cbv_sq_stats* out, int batch, u8* decisions)
+                         cbv_sq_stats* out, int batch, u8* decisions, int want_hough)
 {
     prof_begin(ctx, CBV_K_SQUARES);
     hipLaunchKernelGGL(k_squares_stats, dim3(n, 1, batch), dim3(256), 0, ctx->stream, descs, gray, gray_frame_stride,
-                       ref, mean, var, masks, z_thresh, out, n, decisions);
+                       ref, mean, var, masks, z_thresh, out, n, decisions, want_hough);
     prof_end(ctx, CBV_K_SQUARES);
     CBV_HIP(ctx, hipGetLastError());
     return CBV_OK;

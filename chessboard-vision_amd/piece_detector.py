@@ -5,9 +5,10 @@ The GPU produces, for every square, the preprocessed gray image (BGR2GRAY +
 needs; the chain itself (thresholds, temporal smoothing, reference refresh)
 runs here with the reference's own arithmetic (float64 means, np.var).
 
-Not reproduced: cv2.HoughCircles (piece_detector.py:210-270).  `has_piece` is
-the OR of Hough, centre-vs-border and radial symmetry; this class evaluates the
-latter two, so `method` is never 'hough'/'tower_top' (SURVEY.md H2).
+cv2.HoughCircles (piece_detector.py:210-270) runs on the device as well
+(k_hough.hip): the transform is restated from the published OpenCV 4.x
+algorithm and is bit-identical to this repository's oracle, but no OpenCV
+output was available to pin it against ("parity unpinned").
 """
 import json
 import os
@@ -15,7 +16,7 @@ import os
 import numpy as np
 
 from . import _native as N
-from ._squares import REF, PlaneDict, SquareSet
+from ._squares import GRAY, REF, PlaneDict, SquareSet
 
 SETTINGS_FILE = "piece_detector_settings.json"
 
@@ -54,14 +55,32 @@ class PieceDetectorHIP:
                 print(f"[PieceDetector] Error loading settings: {e}")
 
     # -- decision chain on device statistics ----------------------------------
-    def _decide(self, st, shape):
-        """piece_detector.py:289-345 for one square given its cbv_sq_stats."""
+    def _hough_kwargs(self):
+        return dict(dp=1.2, param1=getattr(self, "hough_param1", 100), param2=getattr(self, "hough_param2", 25),
+                    min_radius_ratio=self.min_radius_ratio, max_radius_ratio=self.max_radius_ratio)
+
+    def _detect_circle_unified(self, gray):
+        """(found, center, radius, type) like piece_detector.py:210-270, for one preprocessed gray square."""
+        self._scratch.load({0: gray}, 5)          # geometry; the plane is replaced by `gray` as given
+        self._scratch.set(GRAY, 0, gray)
+        hg = self._scratch.hough(**self._hough_kwargs())[0]
+        if not hg.found:
+            return False, None, None, None
+        return True, (int(hg.cx), int(hg.cy)), int(hg.r), ("tower_top" if hg.kind == 2 else "hough")
+
+    def _decide(self, st, shape, hg=None):
+        """piece_detector.py:289-345 for one square given its cbv_sq_stats and cbv_hough_result."""
         h, w = shape
         result = {"has_piece": False, "confidence": 0.0, "center": None, "radius": None, "method": None,
                   "center_border_diff": 0, "is_ellipse": False, "axes": None}
         n, s, ss = int(st.n), int(st.sum), int(st.sumsq)
         # np.std(gray) < 15  <=>  n*sumsq - sum^2 < 225 n^2
         if n * ss - s * s < 225 * n * n:
+            return result
+        if hg is not None and hg.found:
+            kind = "tower_top" if hg.kind == 2 else "hough"
+            result.update(has_piece=True, center=(int(hg.cx), int(hg.cy)), radius=int(hg.r), method=kind,
+                          confidence=0.9 if kind == "hough" else 0.75)
             return result
         center_mean = np.float64(st.center_sum) / st.center_cnt if st.center_cnt else np.float64("nan")
         border_mean = np.float64(st.border_sum) / st.border_cnt if st.border_cnt else np.float64("nan")
@@ -90,7 +109,8 @@ class PieceDetectorHIP:
             part = {i: im for i, im in enumerate(imgs[i0:i0 + N.MAX_SQUARES])}
             self._scratch.load(part, 5)
             st = self._scratch.stats()
-            out += [self._decide(st[i], self._scratch.shapes[i]) for i in range(len(part))]
+            hg = self._scratch.hough(**self._hough_kwargs())
+            out += [self._decide(st[i], self._scratch.shapes[i], hg[i]) for i in range(len(part))]
         return out
 
     def detect_piece(self, square_img, pos=None):
@@ -105,8 +125,9 @@ class PieceDetectorHIP:
         self._state.set_ref(None)
         self.reference_squares._mark(self._state.keys)
         st = self._state.stats()
+        hg = self._state.hough(**self._hough_kwargs())
         for i, pos in enumerate(self._state.keys):
-            self.cached_results[pos] = self._decide(st[i], self._state.shapes[i])
+            self.cached_results[pos] = self._decide(st[i], self._state.shapes[i], hg[i])
 
     def update_references(self, squares_dict):
         """piece_detector.py:447-453"""
@@ -141,6 +162,7 @@ class PieceDetectorHIP:
             return results, visual_changes
         self._load_state(squares_dict)
         st = self._state.stats(use_ref=bool(self.reference_squares))
+        hg = self._state.hough(**self._hough_kwargs())
         for pos in squares_dict:
             i = self._state.index[pos]
             s = st[i]
@@ -153,7 +175,7 @@ class PieceDetectorHIP:
                 if pos not in self.cached_results or has_changed_visual:
                     should_process = True
             if should_process or pos not in self.cached_results:
-                raw_result = self._decide(s, shape)
+                raw_result = self._decide(s, shape, hg[i])
                 self.cached_results[pos] = raw_result.copy()
             else:
                 raw_result = self.cached_results[pos].copy()

@@ -123,7 +123,7 @@ CBV_API const char* cbv_device_name(const cbv_ctx* ctx);
 enum {
     CBV_K_COLOR_LAB_HIST = 0, CBV_K_CLAHE_LUT, CBV_K_CLAHE_APPLY, CBV_K_BILATERAL, CBV_K_SHARPEN,
     CBV_K_NORM_LUT, CBV_K_NORMALIZE, CBV_K_WARP, CBV_K_SQUARES, CBV_K_GRAY_BLUR, CBV_K_OTSU,
-    CBV_K_THRESHOLD, CBV_K_SCAN, CBV_K_SYNTH, CBV_K_RESET, CBV_K_COUNT
+    CBV_K_THRESHOLD, CBV_K_SCAN, CBV_K_SYNTH, CBV_K_RESET, CBV_K_HOUGH, CBV_K_COUNT
 };
 CBV_API int cbv_profile_enable(cbv_ctx* ctx, int kid /* -1 = all, -2 = none */);
 CBV_API int cbv_profile_read(cbv_ctx* ctx, int kid, double* total_ms, long long* launches);
@@ -188,6 +188,33 @@ CBV_API int cbv_squares_set_ref(cbv_squares* sq, const uint8_t* select);
 /* statistics of the current gray of every square; use_ref / use_model say
  * whether sad_ref / z_* are wanted (they need set_ref / calibrate first). */
 CBV_API int cbv_squares_stats(cbv_squares* sq, int use_ref, int use_model, double z_threshold, cbv_sq_stats* out);
+
+/* PieceDetector._detect_circle_unified (piece_detector.py:210-270): cv2.HoughCircles(gray,
+ * HOUGH_GRADIENT, dp, minDist = min_dim // 3, param1, param2, minRadius = int(min_dim * min_radius_ratio),
+ * maxRadius = int(min_dim * max_radius_ratio)) on every loaded square's preprocessed gray, then the
+ * circle nearest to (w // 2, h // 2) within 0.3 * min_dim.  The transform is restated from the
+ * published OpenCV 4.x algorithm (parity unpinned). */
+typedef struct {
+    double dp;                 /* 1.2  piece_detector.py:234 */
+    double param1, param2;     /* 100, 25  piece_detector.py:229-230 */
+    double min_radius_ratio;   /* 0.20, or piece_detector_settings.json min_radius / 100 */
+    double max_radius_ratio;   /* 0.55 */
+} cbv_hough_params;
+#define CBV_HOUGH_KEEP 6
+#define CBV_HOUGH_OVERFLOW 1 /* more than 512 accumulator maxima, the rest were dropped */
+#define CBV_HOUGH_SKIPPED 2  /* pipeline only: the statistics-based detectors already decided the square */
+typedef struct {
+    uint8_t found;             /* _detect_circle_unified's `found` */
+    uint8_t kind;              /* 1 'hough', 2 'tower_top' */
+    uint16_t n_circles;        /* circles HoughCircles returned for the square */
+    float cx, cy, r;           /* the chosen circle (float32, before the reference's int()) */
+    int32_t votes;
+    uint32_t n_edges;          /* Canny edge pixels */
+    uint16_t n_centres;        /* accumulator maxima above param2 */
+    uint16_t flags;            /* CBV_HOUGH_* */
+    float circles[CBV_HOUGH_KEEP][4]; /* first circles in HoughCircles' order: x, y, r, support */
+} cbv_hough_result;
+CBV_API int cbv_squares_hough(cbv_squares* sq, const cbv_hough_params* prm, cbv_hough_result* out);
 /* download / upload per-square planes (tight w*h): which = 0 gray(u8) 1 ref(u8) 2 mean(f32) 3 var(f32) */
 CBV_API int cbv_squares_get(cbv_squares* sq, int which, int index, void* out);
 CBV_API int cbv_squares_set(cbv_squares* sq, int which, int index, const void* in);
@@ -215,6 +242,10 @@ typedef struct {
     double initial_variance;     /* 100  change_detector.py:24 */
     int32_t keep_enhanced;       /* 1: materialise process_pipeline's output per frame (cbv_pipeline_download
                                     which = 1); 0: fold the final normalize into the warp gather */
+    int32_t use_hough;           /* 1: detect_piece includes HoughCircles (piece_detector.py:308-317).  has_piece is
+                                    an OR of three detectors, so the transform runs only on the squares the other
+                                    two left undecided; 2: run it on every non-uniform square (inspection) */
+    cbv_hough_params hough;
 } cbv_pipeline_config;
 
 /* Per frame result of PieceDetector.detect_all_pieces(use_smoothing=True,
@@ -281,6 +312,8 @@ CBV_API int cbv_pipeline_noise_results(cbv_pipeline* p, int slot0, int count, cb
 /* download intermediates of one slot for parity checks: which = 0 input, 1 enhanced, 2 warped */
 CBV_API int cbv_pipeline_download(cbv_pipeline* p, int which, int slot, uint8_t* out);
 CBV_API int cbv_pipeline_square_stats(cbv_pipeline* p, int slot, cbv_sq_stats* out /* n_rois */);
+/* HoughCircles outcome of one processed slot (cfg.use_hough): CBV_MAX_SQUARES entries, index = roi */
+CBV_API int cbv_pipeline_hough(cbv_pipeline* p, int slot, cbv_hough_result* out);
 
 #ifdef __cplusplus
 }

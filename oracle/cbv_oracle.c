@@ -16,8 +16,8 @@
  *   - closed-form known-answer tests.
  * For every other stage (colour conversions, CLAHE, bilateral, normalise,
  * warp, Otsu) the status is "PARITY UNPINNED": no OpenCV output exists in
- * this environment to compare with.  HoughCircles (piece_detector.py:232-241)
- * is not restated.
+ * this environment to compare with.  That includes HoughCircles
+ * (piece_detector.py:232-241), restated at the end of this file.
  *
  * Floating point: compiled with -ffp-contract=off, so nothing is fused unless
  * written as fmaf().  Float ops follow OpenCV 4.x's code paths one rounding
@@ -30,6 +30,7 @@
  * Each function cites the reference file:line whose cv2/numpy call it
  * restates.
  */
+#define _GNU_SOURCE
 #include <stdint.h>
 #include <stddef.h>
 #include <stdlib.h>
@@ -1111,4 +1112,247 @@ ORC_API void orc_synth_frame(uint64_t seed, int w, int h, const double* Hinv, co
             }
         }
     }
+}
+
+/* ------------------------------------------------------------------ */
+/* A15 cv2.HoughCircles(gray, HOUGH_GRADIENT, dp, minDist, param1,     */
+/* param2, minRadius, maxRadius) (piece_detector.py:232-241).          */
+/* Restated from the published OpenCV 4.x algorithm (hough.cpp:        */
+/* HoughCirclesGradient): Sobel 3x3 (BORDER_REPLICATE) -> Canny on     */
+/* (dx, dy) with L1 magnitude, thresholds max(1, param1/2) and param1  */
+/* -> gradient-line voting into a 1/dp accumulator (SHIFT = 10 fixed   */
+/* point) -> local maxima above param2, sorted by votes -> per centre  */
+/* radius histogram (10 bins per dp) -> support > param2 -> sort by    */
+/* support, suppress centres closer than minDist.                      */
+/* PARITY UNPINNED: no OpenCV output is available to compare with.     */
+/* ------------------------------------------------------------------ */
+typedef struct { float x, y, r; int votes; } orc_circle;
+
+static void orc_sobel3(const u8* g, int w, int h, short* dx, short* dy)
+{
+    for (int y = 0; y < h; y++) {
+        int ym = y > 0 ? y - 1 : 0, yp = y < h - 1 ? y + 1 : h - 1;
+        for (int x = 0; x < w; x++) {
+            int xm = x > 0 ? x - 1 : 0, xp = x < w - 1 ? x + 1 : w - 1;
+            int a = g[ym * w + xm], b = g[ym * w + x], c = g[ym * w + xp];
+            int d = g[y * w + xm], f = g[y * w + xp];
+            int p = g[yp * w + xm], q = g[yp * w + x], r = g[yp * w + xp];
+            dx[y * w + x] = (short)((c - a) + 2 * (f - d) + (r - p));
+            dy[y * w + x] = (short)((p - a) + 2 * (q - b) + (r - c));
+        }
+    }
+}
+
+/* Canny(dx, dy, low, high, L2gradient = false): edges[] = 255 / 0 */
+static void orc_canny(const short* dx, const short* dy, int w, int h, int low, int high, u8* edges)
+{
+    const int TG22 = (int)(0.4142135623730950488016887242097 * (1 << 15) + 0.5);
+    int pw = w + 2;
+    int* mag = (int*)calloc((size_t)pw * (h + 2), sizeof(int));
+    u8* map = (u8*)malloc((size_t)pw * (h + 2)); /* 0 weak candidate, 1 not an edge, 2 edge */
+    memset(map, 1, (size_t)pw * (h + 2));
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) mag[(y + 1) * pw + x + 1] = abs((int)dx[y * w + x]) + abs((int)dy[y * w + x]);
+    int* stack = (int*)malloc(sizeof(int) * (size_t)w * h);
+    int sp = 0;
+    for (int y = 0; y < h; y++) {
+        for (int x = 0; x < w; x++) {
+            int idx = (y + 1) * pw + x + 1;
+            int m = mag[idx];
+            if (m <= low) continue;
+            int xs = dx[y * w + x], ys = dy[y * w + x];
+            int ax = abs(xs), ay = abs(ys) << 15;
+            int tg22x = ax * TG22;
+            int keep = 0;
+            if (ay < tg22x) {
+                keep = m > mag[idx - 1] && m >= mag[idx + 1];
+            } else {
+                int tg67x = tg22x + (ax << 16);
+                if (ay > tg67x) keep = m > mag[idx - pw] && m >= mag[idx + pw];
+                else {
+                    int s = (xs ^ ys) < 0 ? -1 : 1;
+                    keep = m > mag[idx - pw - s] && m > mag[idx + pw + s];
+                }
+            }
+            if (!keep) continue;
+            if (m > high) {
+                map[idx] = 2;
+                stack[sp++] = idx;
+            } else map[idx] = 0;
+        }
+    }
+    while (sp > 0) {
+        int idx = stack[--sp];
+        static const int dxs[8] = {-1, 0, 1, -1, 1, -1, 0, 1}, dys[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+        for (int k = 0; k < 8; k++) {
+            int n = idx + dys[k] * pw + dxs[k];
+            if (map[n] == 0) {
+                map[n] = 2;
+                stack[sp++] = n;
+            }
+        }
+    }
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) edges[y * w + x] = map[(y + 1) * pw + x + 1] == 2 ? 255 : 0;
+    free(mag);
+    free(map);
+    free(stack);
+}
+
+static int cmp_center(const void* a, const void* b, void* acc)
+{
+    const int* A = (const int*)acc;
+    int l1 = *(const int*)a, l2 = *(const int*)b;
+    if (A[l1] != A[l2]) return A[l1] > A[l2] ? -1 : 1;
+    return l1 < l2 ? -1 : (l1 > l2 ? 1 : 0);
+}
+static int cmp_circle(const void* a, const void* b)
+{
+    const orc_circle *L = (const orc_circle*)a, *R = (const orc_circle*)b;
+    if (L->votes != R->votes) return L->votes > R->votes ? -1 : 1;
+    if (L->r != R->r) return L->r > R->r ? -1 : 1;
+    if (L->x != R->x) return L->x < R->x ? -1 : 1;
+    if (L->y != R->y) return L->y < R->y ? -1 : 1;
+    return 0;
+}
+static inline int cv_ceil_f(float v) { int i = (int)v; return i + (i < v); }
+
+ORC_API int orc_hough_circles(const u8* gray, int w, int h, double dp_d, double min_dist_d, double param1,
+                              double param2, int min_radius, int max_radius, orc_circle* out, int max_out,
+                              u8* edges_out)
+{
+    float dp = (float)dp_d;
+    if (dp < 1.f) dp = 1.f;
+    const float idp = 1.f / dp;
+    int canny_thr = cv_round_d(param1), acc_thr = cv_round_d(param2);
+    if (min_radius < 0) min_radius = 0;
+    if (max_radius <= 0) max_radius = w > h ? w : h;
+    else if (max_radius <= min_radius) max_radius = min_radius + 2;
+    short* dx = (short*)malloc(sizeof(short) * (size_t)w * h);
+    short* dy = (short*)malloc(sizeof(short) * (size_t)w * h);
+    u8* edges = (u8*)malloc((size_t)w * h);
+    orc_sobel3(gray, w, h, dx, dy);
+    int low = canny_thr / 2;
+    if (low < 1) low = 1;
+    orc_canny(dx, dy, w, h, low, canny_thr, edges);
+    if (edges_out) memcpy(edges_out, edges, (size_t)w * h);
+    const int SHIFT = 10, ONE = 1 << SHIFT;
+    int arows = cv_ceil_f(h * idp), acols = cv_ceil_f(w * idp), astep = acols + 2;
+    int* acc = (int*)calloc((size_t)(arows + 2) * astep, sizeof(int));
+    int* nzx = (int*)malloc(sizeof(int) * (size_t)w * h);
+    int* nzy = (int*)malloc(sizeof(int) * (size_t)w * h);
+    int nz = 0;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            if (!edges[y * w + x]) continue;
+            float vx = dx[y * w + x], vy = dy[y * w + x];
+            if (vx == 0 && vy == 0) continue;
+            float mag = sqrtf(vx * vx + vy * vy);
+            if (mag < 1.0f) continue;
+            nzx[nz] = x;
+            nzy[nz] = y;
+            nz++;
+            int sx = cv_round_f((vx * idp) * ONE / mag);
+            int sy = cv_round_f((vy * idp) * ONE / mag);
+            int x0 = cv_round_f((x * idp) * ONE);
+            int y0 = cv_round_f((y * idp) * ONE);
+            for (int k1 = 0; k1 < 2; k1++) {
+                int x1 = x0 + min_radius * sx, y1 = y0 + min_radius * sy;
+                for (int r = min_radius; r <= max_radius; x1 += sx, y1 += sy, r++) {
+                    int x2 = x1 >> SHIFT, y2 = y1 >> SHIFT;
+                    if ((unsigned)x2 >= (unsigned)acols || (unsigned)y2 >= (unsigned)arows) break;
+                    acc[y2 * astep + x2]++;
+                }
+                sx = -sx;
+                sy = -sy;
+            }
+        }
+    int ncirc = 0;
+    orc_circle* circ = NULL;
+    if (nz > 0) {
+        int* centers = (int*)malloc(sizeof(int) * (size_t)(arows + 2) * astep);
+        int nc = 0;
+        for (int y = 1; y < arows + 1; y++)
+            for (int x = 1; x <= acols; x++) {
+                int base = y * astep + x;
+                if (acc[base] > acc_thr && acc[base] > acc[base - 1] && acc[base] >= acc[base + 1] &&
+                    acc[base] > acc[base - astep] && acc[base] >= acc[base + astep])
+                    centers[nc++] = base;
+            }
+        qsort_r(centers, nc, sizeof(int), cmp_center, acc);
+        const int nBinsPerDr = 10;
+        const int nBins = cv_round_f((max_radius - min_radius) / dp * nBinsPerDr);
+        int* bins = (int*)malloc(sizeof(int) * (nBins > 0 ? nBins : 1));
+        circ = (orc_circle*)malloc(sizeof(orc_circle) * (nc > 0 ? nc : 1));
+        const float minR2 = (float)min_radius * min_radius, maxR2 = (float)max_radius * max_radius;
+        for (int i = 0; i < nc; i++) {
+            int ofs = centers[i];
+            int cy = ofs / astep, cx = ofs - cy * astep;
+            float ccx = (cx + 0.5f) * dp, ccy = (cy + 0.5f) * dp;
+            int max_count = 0;
+            float r_best = 0;
+            int cnt = 0;
+            memset(bins, 0, sizeof(int) * (nBins > 0 ? nBins : 1));
+            for (int j = 0; j < nz; j++) {
+                float ddx = ccx - nzx[j], ddy = ccy - nzy[j];
+                float r2 = ddx * ddx + ddy * ddy;
+                if (minR2 <= r2 && r2 <= maxR2) {
+                    int bin = cv_round_f((sqrtf(r2) - min_radius) / dp * nBinsPerDr);
+                    if (bin > nBins - 1) bin = nBins - 1;
+                    if (bin < 0) bin = 0;
+                    bins[bin]++;
+                    cnt++;
+                }
+            }
+            if (cnt) {
+                for (int j = nBins - 1; j > 0; j--) {
+                    if (bins[j]) {
+                        int upbin = j, cur = 0;
+                        for (; j > upbin - nBinsPerDr && j >= 0; j--) cur += bins[j];
+                        float r_cur = (upbin + j) / 2.f / nBinsPerDr * dp + min_radius;
+                        if ((cur * r_best >= max_count * r_cur) || (r_best < FLT_EPSILON && cur >= max_count)) {
+                            r_best = r_cur;
+                            max_count = cur;
+                        }
+                    }
+                }
+            }
+            if (max_count > acc_thr) {
+                circ[ncirc].x = ccx;
+                circ[ncirc].y = ccy;
+                circ[ncirc].r = r_best;
+                circ[ncirc].votes = max_count;
+                ncirc++;
+            }
+        }
+        qsort(circ, ncirc, sizeof(orc_circle), cmp_circle);
+        /* RemoveOverlaps */
+        float md = (float)min_dist_d;
+        if (md < dp) md = dp;
+        float md2 = md * md;
+        if (ncirc > 1) {
+            int end = 1;
+            for (int i = 1; i < ncirc; i++) {
+                int close = 0;
+                for (int j = 0; j < end; j++) {
+                    float ddx = circ[j].x - circ[i].x, ddy = circ[j].y - circ[i].y;
+                    if (ddx * ddx + ddy * ddy < md2) { close = 1; break; }
+                }
+                if (!close) circ[end++] = circ[i];
+            }
+            ncirc = end;
+        }
+        free(centers);
+        free(bins);
+    }
+    int n_out = ncirc < max_out ? ncirc : max_out;
+    for (int i = 0; i < n_out; i++) out[i] = circ[i];
+    free(circ);
+    free(acc);
+    free(nzx);
+    free(nzy);
+    free(dx);
+    free(dy);
+    free(edges);
+    return ncirc;
 }

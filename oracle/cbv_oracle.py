@@ -302,3 +302,20 @@ def synth_frame(seed, w, h, Hinv, board, scene):
     out = np.empty((h, w, 3), np.uint8)
     lib().orc_synth_frame(C.c_uint64(seed), w, h, _p(Hinv), _p(board), C.byref(scene), _p(out), out.strides[0])
     return out
+
+
+class Circle(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("r", C.c_float), ("votes", C.c_int)]
+
+
+def hough_circles(gray, dp=1.2, min_dist=25, param1=100, param2=25, min_radius=19, max_radius=42, return_edges=False):
+    """cv2.HoughCircles(gray, HOUGH_GRADIENT, ...) restated (parity unpinned).  Returns [(x, y, r, votes)]."""
+    gray = np.ascontiguousarray(_u8(gray))
+    h, w = gray.shape
+    out = (Circle * 64)()
+    edges = np.empty((h, w), np.uint8)
+    lib().orc_hough_circles.restype = C.c_int
+    n = lib().orc_hough_circles(_p(gray), w, h, C.c_double(dp), C.c_double(min_dist), C.c_double(param1), C.c_double(param2),
+                                int(min_radius), int(max_radius), out, 64, _p(edges))
+    res = [(out[i].x, out[i].y, out[i].r, out[i].votes) for i in range(min(n, 64))]
+    return (res, edges) if return_edges else res

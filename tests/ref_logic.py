@@ -8,7 +8,28 @@ import numpy as np
 from oracle import cbv_oracle as O
 
 
-def detect_piece(square_img, circle_threshold=0.6):
+def detect_circle_unified(gray, min_radius_ratio=0.20, max_radius_ratio=0.55, param1=100, param2=25):
+    """piece_detector.py:210-270 on the oracle's HoughCircles restatement (numpy float32 arithmetic for the pick,
+    as `cx`, `cy` are float32 there)."""
+    h, w = gray.shape
+    min_dim = min(h, w)
+    circles = O.hough_circles(gray, 1.2, min_dim // 3, param1, param2, int(min_dim * min_radius_ratio), int(min_dim * max_radius_ratio))
+    best, best_dist = None, float("inf")
+    max_offset = min_dim * 0.3
+    for (cx, cy, r, _) in circles:
+        cx, cy = np.float32(cx), np.float32(cy)
+        dist = np.sqrt((cx - (w // 2)) ** 2 + (cy - (h // 2)) ** 2)
+        if dist < max_offset and dist < best_dist:
+            best_dist, best = dist, (cx, cy, np.float32(r))
+    if best is None:
+        return False, None, None, None, circles
+    r = int(best[2])
+    kind = "tower_top" if r < min_dim * 0.20 else "hough"
+    return True, (int(best[0]), int(best[1])), r, kind, circles
+
+
+def detect_piece(square_img, circle_threshold=0.6, hough=None):
+    """`hough`: None = without the HoughCircles step; else kwargs for detect_circle_unified."""
     gray = O.square_preprocess(square_img, 5)
     h, w = gray.shape
     st = O.square_stats(gray)
@@ -17,6 +38,11 @@ def detect_piece(square_img, circle_threshold=0.6):
     std = np.std(gray)
     if std < 15:
         return res, gray
+    if hough is not None:
+        found, center, radius, kind, _ = detect_circle_unified(gray, **hough)
+        if found:
+            res.update(has_piece=True, center=center, radius=radius, method=kind, confidence=0.9 if kind == "hough" else 0.75)
+            return res, gray
     cm = np.float64(st.center_sum) / st.center_cnt
     bm = np.float64(st.border_sum) / st.border_cnt
     diff = abs(cm - bm)
@@ -32,7 +58,8 @@ def detect_piece(square_img, circle_threshold=0.6):
 
 
 class RefPieceDetector:
-    def __init__(self):
+    def __init__(self, hough=None):
+        self.hough = hough
         self.history_size, self.min_presence, self.change_threshold = 5, 0.6, 25
         self.detection_history, self.reference_squares, self.cached_results = {}, {}, {}
 
@@ -52,7 +79,7 @@ class RefPieceDetector:
     def detect_all_pieces(self, squares, use_smoothing=True, use_delta=True, squares_to_check=None):
         results, visual = {}, set()
         for pos, img in squares.items():
-            raw, gray = detect_piece(img)
+            raw, gray = detect_piece(img, hough=self.hough)
             changed = True
             if pos in self.reference_squares:
                 diff = np.abs(gray.astype(np.int16) - self.reference_squares[pos].astype(np.int16))
@@ -85,7 +112,8 @@ class RefPieceDetector:
 
 
 class RefChangeDetector:
-    def __init__(self):
+    def __init__(self, hough=None):
+        self.hough = hough
         self.z_threshold, self.initial_variance, self.alpha, self.blur_kernel = 2.5, 100, 0.1, 5
         self.means, self.variances, self.is_calibrated, self.focus_squares = {}, {}, False, set()
 
@@ -122,5 +150,5 @@ class RefChangeDetector:
                 continue
             inten = "TOTAL" if pct > 75 else ("PARCIAL" if pct > 15 else "LEVE")
             out[pos] = {"z_score": float(st.z_max), "pct_changed": pct, "intensity": inten,
-                        "is_circular": detect_piece(squares[pos])[0]["has_piece"], "center_ratio": 1.0}
+                        "is_circular": detect_piece(squares[pos], hough=self.hough)[0]["has_piece"], "center_ratio": 1.0}
         return out

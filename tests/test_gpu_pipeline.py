@@ -20,7 +20,7 @@ def _oracle_chain(oracle, frames, profile, pts, grid_lines=None):
     if grid_lines is not None:
         ge = SmartGridExtractor()
         ge.grid_lines_x, ge.grid_lines_y = list(grid_lines[0]), list(grid_lines[1])
-    det = RefPieceDetector()
+    det = RefPieceDetector(hough={})
     out = []
     for f in frames:
         enh = oracle.process_pipeline(f, profile)
@@ -52,8 +52,10 @@ def test_pipeline_matches_oracle_chain(gpu_ctx, oracle, scene, profile, grid):
         assert bits_to_positions(res[i].stable_occupied, p.rois_rc) == ref[i]["stable"], i
         assert bits_to_positions(res[i].raw_occupied, p.rois_rc) == ref[i]["raw"], i
         assert bits_to_positions(res[i].visual_changes, p.rois_rc) == ref[i]["visual"], i
-        # raw occupancy is the scripted position of that frame -> FEN placement is bit-identical
-        assert ref[i]["raw"] == set(S.position_for_frame(i, 2).keys())
+        # raw occupancy covers the scripted position of that frame; exactly so in the clean scene (in the dim,
+        # noise-amplified scene HoughCircles also fires on a few empty squares, in the oracle and here alike)
+        want = set(S.position_for_frame(i, 2).keys())
+        assert ref[i]["raw"] >= want and (scene == "dim" or ref[i]["raw"] == want)
 
 
 def test_fused_and_unfused_paths_and_lane_counts_agree(gpu_ctx):
@@ -179,7 +181,7 @@ def test_pipeline_change_detector_stage(gpu_ctx, oracle):
     p.reset_state()
     p.run(0, n)
     res = p.results(0, n)
-    ref = RefChangeDetector()
+    ref = RefChangeDetector(hough={})
     ref.z_threshold, ref.initial_variance = 2.55, 600
     seen = set()
     for i in range(n):
@@ -229,3 +231,41 @@ def test_pipeline_noise_stage_matches_host_class(gpu_ctx):
         assert noise[i] == exp, (i, noise[i], exp)
         states.add(exp[0].name)
     assert {"NOISE_ACTIVE", "IDLE", "MOVE_PENDING"} <= states  # first frame = 64 changes (hand), then moves settle
+
+
+def test_pipeline_hough_short_circuit_is_exact(gpu_ctx, oracle):
+    """use_hough=1 runs HoughCircles only where centre-vs-border and radial symmetry left has_piece open;
+    use_hough=2 runs it on every non-uniform square; use_hough=0 not at all.  1 and 2 must agree bit for bit
+    (has_piece is an OR), and wherever the transform ran its outcome equals the oracle's."""
+    from chessboard_vision_amd import _native as N
+    from chessboard_vision_amd.stream import BoardPipeline
+    from ref_logic import detect_circle_unified
+    n = 6
+    pts = S.scaled_corners(W, H)
+    outs, ps = {}, {}
+    for mode in (0, 1, 2):
+        p = BoardPipeline(W, H, n)
+        p.configure(pts, profile=S.SHIPPED_PROFILE, grid_lines=(S.CALIB_GRID_X, S.CALIB_GRID_Y), use_hough=mode, chunk=4)
+        p.synth(0, n, scene="dim", frames_per_ply=2)
+        p.run(0, n)
+        outs[mode] = [(r.raw_occupied, r.stable_occupied, r.visual_changes, r.processed, r.circular) for r in p.results(0, n)]
+        ps[mode] = p
+    assert outs[1] == outs[2]
+    assert outs[0] != outs[1], "the dim scene is chosen so that HoughCircles changes some decisions"
+    with pytest.raises(RuntimeError):
+        ps[0].hough(0)
+    warped = ps[2].download(2, 3)
+    ran = {1: 0, 2: 0}
+    for mode in (1, 2):
+        hg = ps[mode].hough(3)
+        for i, (r, c) in enumerate(ps[mode].rois_rc):
+            if hg[i].flags & N.HOUGH_SKIPPED:
+                continue
+            ran[mode] += 1
+            x0, y0, w, h = (ps[mode]._cfg.rois[i].x0, ps[mode]._cfg.rois[i].y0, ps[mode]._cfg.rois[i].w, ps[mode]._cfg.rois[i].h)
+            gray = oracle.square_preprocess(warped[y0:y0 + h, x0:x0 + w], 5)
+            found, center, radius, kind, circles = detect_circle_unified(gray)
+            assert bool(hg[i].found) == found and hg[i].n_circles == len(circles), (mode, i)
+            if found:
+                assert (int(hg[i].cx), int(hg[i].cy), int(hg[i].r)) == (center[0], center[1], radius), (mode, i)
+    assert 0 < ran[1] < ran[2] <= 64

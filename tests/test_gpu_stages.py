@@ -227,7 +227,7 @@ def _board_squares(oracle, frame_idx, scene="normal", grid="linear"):
 def test_piece_detector_sequence(gpu_ctx, oracle, grid):
     from chessboard_vision_amd.piece_detector import PieceDetector
     from ref_logic import RefPieceDetector
-    gpu, ref = PieceDetector(), RefPieceDetector()
+    gpu, ref = PieceDetector(), RefPieceDetector(hough={})
     sq0 = _board_squares(oracle, 0, grid=grid)
     gpu.update_references(sq0)
     ref.update_references(sq0)
@@ -250,7 +250,7 @@ def test_piece_detector_sequence(gpu_ctx, oracle, grid):
 def test_change_detector_sequence(gpu_ctx, oracle):
     from chessboard_vision_amd.change_detector import ChangeDetector
     from ref_logic import RefChangeDetector
-    gpu, ref = ChangeDetector(), RefChangeDetector()
+    gpu, ref = ChangeDetector(), RefChangeDetector(hough={})
     for blur in (5, 13, 1):
         gpu.blur_kernel = ref.blur_kernel = blur
         gpu.z_threshold = ref.z_threshold = 2.55
@@ -294,3 +294,83 @@ def test_squares_edge_shapes(gpu_ctx, oracle):
             assert list(st[i].ring_sum) == list(ost.ring_sum) and list(st[i].ring_cnt) == list(ost.ring_cnt)
     with pytest.raises(RuntimeError):
         SquareSet().load({0: np.zeros((129, 10), np.uint8)}, 5)
+
+
+def _hough_squares(oracle):
+    """Preprocessed gray squares that exercise HoughCircles: board squares of both scenes (pieces, empty, noisy),
+    drawn discs/rings of several radii and offsets, pure noise, flat, and odd shapes."""
+    rng = np.random.default_rng(11)
+    out = []
+    for scene, prof in (("normal", {}), ("dim", S.SHIPPED_PROFILE)):
+        f = oracle_frame(640, 480, scene, frame_idx=4, frames_per_ply=2)
+        warped, _, _ = oracle.warp_image(oracle.process_pipeline(f, prof), S.scaled_corners(640, 480))
+        for r in (0, 1, 3, 6, 7):
+            for c in (0, 2, 5, 7):
+                out.append(oracle.square_preprocess(warped[r * 77:(r + 1) * 77, c * 77:(c + 1) * 77], 5))
+    yy, xx = np.mgrid[0:77, 0:77]
+    for (cx, cy, rad, fg, bg) in ((38, 38, 30, 220, 60), (30, 44, 22, 40, 200), (38, 38, 14, 250, 20), (60, 20, 25, 200, 90),
+                                  (38, 38, 41, 180, 30), (10, 10, 30, 255, 0)):
+        img = np.where((xx - cx) ** 2 + (yy - cy) ** 2 <= rad * rad, fg, bg).astype(np.uint8)
+        out.append(oracle.gaussian_blur(np.clip(img.astype(np.int16) + rng.integers(-6, 7, img.shape), 0, 255).astype(np.uint8), 5))
+    out.append(oracle.gaussian_blur(rng.integers(0, 256, (77, 77), dtype=np.uint8), 5))
+    out.append(rng.integers(0, 256, (77, 77), dtype=np.uint8))            # unblurred noise: dense edges, many maxima
+    out.append(np.full((77, 77), 128, np.uint8))
+    for (h, w, rad) in ((120, 100, 35), (40, 64, 12), (9, 12, 3), (85, 70, 28), (2, 2, 1), (128, 128, 50)):
+        yy2, xx2 = np.mgrid[0:h, 0:w]
+        img = np.where((xx2 - w // 2) ** 2 + (yy2 - h // 2) ** 2 <= rad * rad, 230, 40).astype(np.uint8)
+        out.append(oracle.gaussian_blur(img, 5) if min(h, w) >= 5 else img)
+    return out
+
+
+@pytest.mark.parametrize("ratios", [(0.20, 0.55), (0.25, 0.55), (0.12, 0.30)])
+def test_hough_circles_match_oracle(gpu_ctx, oracle, ratios):
+    """k_hough vs the oracle's HoughCircles restatement: edge count, every returned circle (bit-equal floats, same
+    order) and the pick of _detect_circle_unified.  PARITY UNPINNED against OpenCV itself (no cv2 here)."""
+    from chessboard_vision_amd._squares import GRAY, SquareSet
+    from ref_logic import detect_circle_unified
+    grays = _hough_squares(oracle)
+    found_any = 0
+    for g0 in range(0, len(grays), 64):
+        part = grays[g0:g0 + 64]
+        ss = SquareSet(gpu_ctx)
+        ss.load({i: g for i, g in enumerate(part)}, 5)
+        for i, g in enumerate(part):
+            ss.set(GRAY, i, g)
+        res = ss.hough(min_radius_ratio=ratios[0], max_radius_ratio=ratios[1])
+        for i, g in enumerate(part):
+            found, center, radius, kind, circles = detect_circle_unified(g, ratios[0], ratios[1])
+            _, edges = oracle.hough_circles(g, 1.2, min(g.shape) // 3, 100, 25, int(min(g.shape) * ratios[0]),
+                                            int(min(g.shape) * ratios[1]), return_edges=True)
+            r = res[i]
+            tag = (g0 + i, g.shape)
+            assert r.flags == 0, tag
+            assert r.n_edges == int((edges > 0).sum()), tag
+            assert r.n_circles == len(circles), (tag, r.n_circles, circles)
+            for k in range(min(len(circles), 6)):
+                got = tuple(np.float32(r.circles[k][j]) for j in range(4))
+                want = tuple(np.float32(v) for v in circles[k])
+                assert got == want, (tag, k, got, want)
+            assert bool(r.found) == found, tag
+            if found:
+                found_any += 1
+                assert (int(r.cx), int(r.cy)) == center and int(r.r) == radius, tag
+                assert ("tower_top" if r.kind == 2 else "hough") == kind, tag
+    assert found_any >= (10 if ratios[1] > 0.5 else 3)
+
+
+def test_detect_piece_reports_hough_method(gpu_ctx, oracle):
+    """piece_detector.py:308-317: a found circle short-circuits with method 'hough' / 'tower_top'."""
+    from chessboard_vision_amd.piece_detector import PieceDetector
+    from ref_logic import detect_piece
+    det = PieceDetector()
+    sq = _board_squares(oracle, 0)
+    methods = set()
+    for pos, img in sq.items():
+        got, want = det.detect_piece(img, pos), detect_piece(img, hough={})[0]
+        assert got == want, (pos, got, want)
+        methods.add(got["method"])
+    assert "hough" in methods
+    gray = oracle.square_preprocess(sq[(4, 0)], 5)
+    from ref_logic import detect_circle_unified
+    assert det._detect_circle_unified(gray) == detect_circle_unified(gray)[:4]
+

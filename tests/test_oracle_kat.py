@@ -194,3 +194,55 @@ def test_synthetic_frame_is_deterministic_and_has_a_board():
     c = oracle_frame(320, 240, "normal", frame_idx=1)
     assert np.array_equal(a, b) and not np.array_equal(a, c)
     assert a[120, 180].max() > 100  # inside the board quad
+
+
+def test_hough_canny_step_edge(oracle):
+    """Canny inside HoughCircles: a vertical step of height 200 gives |dx| = 800 on the two columns at the step;
+    non-maximum suppression (m > left, m >= right) keeps the left one, replicate borders keep it straight."""
+    g = np.zeros((20, 30), np.uint8)
+    g[:, 15:] = 200
+    _, edges = oracle.hough_circles(g, 1.2, 6, 100, 25, 4, 11, return_edges=True)
+    want = np.zeros_like(g)
+    want[:, 14] = 255
+    assert np.array_equal(edges, want)
+    # a ramp whose gradient never exceeds param1 / 2 has no edges at all
+    ramp = np.tile((np.arange(30) * 4).astype(np.uint8), (20, 1))
+    _, e2 = oracle.hough_circles(ramp, 1.2, 6, 100, 25, 4, 11, return_edges=True)
+    assert not e2.any()
+
+
+@pytest.mark.parametrize("cx,cy,rad", [(38, 38, 30), (30, 44, 22), (45, 33, 26)])
+def test_hough_recovers_a_drawn_disc(oracle, cx, cy, rad):
+    """Known-answer property of the restated HoughCircles: a clean blurred disc comes back as the first circle,
+    centre within one accumulator cell (dp = 1.2) and radius within 2 px."""
+    yy, xx = np.mgrid[0:77, 0:77]
+    img = np.where((xx - cx) ** 2 + (yy - cy) ** 2 <= rad * rad, 220, 50).astype(np.uint8)
+    circles = oracle.hough_circles(oracle.gaussian_blur(img, 5), 1.2, 25, 100, 25, 15, 42)
+    assert circles, "no circle found"
+    x, y, r, votes = circles[0]
+    assert abs(x - cx) <= 1.8 and abs(y - cy) <= 1.8 and abs(r - rad) <= 2.0 and votes > 25
+    # circles come back sorted by support, centres at least minDist apart
+    for a in range(len(circles)):
+        for b in range(a):
+            assert (circles[a][0] - circles[b][0]) ** 2 + (circles[a][1] - circles[b][1]) ** 2 >= 25 * 25
+            assert circles[b][3] >= circles[a][3]
+
+
+def test_hough_flat_and_tiny(oracle):
+    assert oracle.hough_circles(np.full((77, 77), 90, np.uint8)) == []
+    assert oracle.hough_circles(np.array([[0, 255], [255, 0]], np.uint8), 1.2, 0, 100, 25, 0, 1) == []
+
+
+def test_detect_piece_hough_branch(oracle):
+    """piece_detector.py:308-317: a found circle short-circuits with 'hough' (r >= 20 % of the square) or
+    'tower_top' (smaller); the uniformity pre-filter still comes first."""
+    from ref_logic import detect_piece
+    yy, xx = np.mgrid[0:77, 0:77]
+    big = np.dstack([np.where((xx - 38) ** 2 + (yy - 38) ** 2 <= 30 * 30, 220, 50).astype(np.uint8)] * 3)
+    small = np.dstack([np.where((xx - 38) ** 2 + (yy - 38) ** 2 <= 12 * 12, 230, 40).astype(np.uint8)] * 3)
+    r_big = detect_piece(big, hough={})[0]
+    assert r_big["has_piece"] and r_big["method"] == "hough" and r_big["confidence"] == 0.9 and abs(r_big["radius"] - 30) <= 2
+    r_small = detect_piece(small, hough=dict(min_radius_ratio=0.12, max_radius_ratio=0.25))[0]
+    assert r_small["has_piece"] and r_small["method"] == "tower_top" and r_small["confidence"] == 0.75
+    flat = np.full((77, 77, 3), 100, np.uint8)
+    assert detect_piece(flat, hough={})[0]["has_piece"] is False
