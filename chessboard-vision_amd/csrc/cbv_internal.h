@@ -195,6 +195,7 @@ struct HoughCfg {
     int canny_thr, acc_thr;
     double min_ratio, max_ratio;
     int maxw, maxh; // largest square of the set
+    int gs, mw, mag_bytes; // padded row strides of the gray/map planes (bytes) and the magnitude plane (u16)
     int off_map, off_mag, off_acc, off_centres, off_bins, off_order, max_bins;
 };
 // `decisions` (may be null): squares whose byte lacks bit 4 are skipped; a found circle sets bit 0.

@@ -8,13 +8,15 @@ from chessboard_vision_amd.stream import BoardPipeline
 n = 32
 p = BoardPipeline(1920, 1080, n)
 p.configure(S.scaled_corners(1920, 1080), profile=S.SHIPPED_PROFILE, grid_lines=(S.CALIB_GRID_X, S.CALIB_GRID_Y),
-            min_radius_ratio=0.25, chunk=32, lanes=1)
+            min_radius_ratio=0.25, chunk=32, lanes=1, use_hough=2)
 p.synth(0, n, scene="dim", frames_per_ply=4)
 p.run(0, n)
 p.results(0, n)
 rows = []
 for slot in (0, 13, 31):
     for r in p.hough(slot):
+        if r.flags & 2:
+            continue
         t = [r.circles[2 + i // 4][i % 4] for i in range(8)] + [r.circles[4][0]]
         rows.append(t + [r.n_edges, r.n_centres, r.circles[4][1], r.circles[4][2], r.found])
 a = np.array(rows)
