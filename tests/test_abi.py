@@ -11,9 +11,12 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_symbols():
-    txt = open(os.path.join(ROOT, "include", "cbv.h")).read()
-    return re.findall(r"^CBV_API\s+[\w\s\*]+?\b(cbv_\w+)\s*\(", txt, flags=re.M)
+def header_symbols(names=("cbv.h", "cbv_chess.h")):
+    out = []
+    for name in names:
+        txt = open(os.path.join(ROOT, "include", name)).read()
+        out += re.findall(r"^CBV_API\s+[\w\s\*]+?\b(cbv_\w+)\s*\(", txt, flags=re.M)
+    return out
 
 
 def test_header_declares_the_boundary():
@@ -25,7 +28,9 @@ def test_header_declares_the_boundary():
 
 def test_library_exports_every_declared_symbol():
     from chessboard_vision_amd import _native as N
+    from chessboard_vision_amd import chess_rules
     lib = N.load()
+    chess_rules._L()
     for s in header_symbols():
         assert hasattr(lib, s), "libcbv_hip.so does not export %s" % s
         assert getattr(lib, s).argtypes is not None or s in ("cbv_device_count",), "no prototype bound for %s" % s

@@ -269,3 +269,25 @@ def test_pipeline_hough_short_circuit_is_exact(gpu_ctx, oracle):
             if found:
                 assert (int(hg[i].cx), int(hg[i].cy), int(hg[i].r)) == (center[0], center[1], radius), (mode, i)
     assert 0 < ran[1] < ran[2] <= 64
+
+
+def test_pipeline_occupancy_drives_game_state(gpu_ctx):
+    """SURVEY f1 on top of the path: per-frame occupancy words -> GameState (native rules engine) -> moves and a
+    FEN with piece identity, for the scripted game."""
+    from chessboard_vision_amd import chess_rules as chess
+    from chessboard_vision_amd.game_state import GameState
+    from chessboard_vision_amd.stream import BoardPipeline
+    fpp, n = 3, 3 * 16 + 2
+    p = BoardPipeline(W, H, n)
+    p.configure(S.scaled_corners(W, H), profile={}, chunk=16)
+    p.synth(0, n, scene="normal", frames_per_ply=fpp)
+    p.run(0, n)
+    gs, played = GameState(), []
+    for r in p.results(0, n):
+        move, status = gs.process_occupancy_bits(chess.roi_bits_to_squares(r.raw_occupied))
+        if move is not None:
+            played.append((move.uci(), status))
+    assert [m for m, _ in played] == ["e2e4", "e7e5", "g1f3", "b8c6", "f1b5", "a7a6", "b5a4", "g8f6", "e1g1", "f8e7",
+                                      "f1e1", "b7b5", "a4b3", "d7d6", "c2c3", "e8g8"]
+    assert [s for _, s in played].count("castling_confirmed") == 2
+    assert gs.get_fen() == "r1bq1rk1/2p1bppp/p1np1n2/1p2p3/4P3/1BP2N2/PP1P1PPP/RNBQR1K1 w - - 1 9"
