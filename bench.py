@@ -58,7 +58,7 @@ def cpu_baseline(w, h, n_frames, profile, pts, grid_lines):
     frames = [oracle_frame(w, h, "dim", frame_idx=i) for i in range(n_frames)]
     ge = SmartGridExtractor()
     ge.grid_lines_x, ge.grid_lines_y = list(grid_lines[0]), list(grid_lines[1])
-    det = RefPieceDetector()
+    det = RefPieceDetector(hough=dict(S.SHIPPED_DETECTOR))
     t0 = time.perf_counter()
     occ = None
     for f in frames:
@@ -122,7 +122,7 @@ def main():
     profile = S.SHIPPED_PROFILE
 
     pipe = BoardPipeline(w, h, F, ctx)
-    pipe.configure(pts, profile=profile, grid_lines=grid, chunk=args.chunk, lanes=args.lanes)
+    pipe.configure(pts, profile=profile, grid_lines=grid, chunk=args.chunk, lanes=args.lanes, **S.SHIPPED_DETECTOR)
     pipe.synth(0, F, stream_id=rank, scene="dim")  # inputs resident in HBM before the timed region
     chunk = pipe._cfg.chunk if pipe._cfg.chunk > 0 else 32
 
@@ -157,6 +157,7 @@ def main():
     ctx.profile_enable(-2)
 
     res = pipe.results(0, F)
+    hough_ran = sum(1 for r in pipe.hough(F - 1) if not (r.flags & N.HOUGH_SKIPPED))  # squares HoughCircles had to decide
     occ_ok = pipe.occupied(res[F - 1]) == set(S.position_for_frame(F - 1).keys())
     if not occ_ok and rank == 0:
         got, exp = pipe.occupied(res[F - 1]), set(S.position_for_frame(F - 1).keys())
@@ -170,7 +171,7 @@ def main():
     if rank == 0 and not args.no_profile_pass:
         # one extra, untimed pass with events around every kernel, on ONE lane so that kernels of
         # different chunks do not overlap and each duration is the kernel's own
-        pipe.configure(pts, profile=profile, grid_lines=grid, chunk=args.chunk, lanes=1)
+        pipe.configure(pts, profile=profile, grid_lines=grid, chunk=args.chunk, lanes=1, **S.SHIPPED_DETECTOR)
         pipe.run(0, 1)
         pipe.calibrate_changes(0)
         pipe.run(0, F)
@@ -246,6 +247,7 @@ def main():
             "path_roofline": {"alg_bytes_per_frame": path_bytes, "achieved": round(path_bytes * fps / world / 1e9, 2), "peak": HBM_PEAK_GBPS,
                               "unit": "GB/s", "frac": round(path_bytes * fps / world / 1e9 / HBM_PEAK_GBPS, 5)},
             "kernels": kernels, "single_frame_ms": single_ms, "cpu_baseline": cpu, "occupancy_check": bool(occ_ok),
+            "hough_squares_last_frame": hough_ran,
             "device": ctx.name,
         }
         sys.stdout.flush()

@@ -536,7 +536,7 @@ extern "C" void cbv_squares_destroy(cbv_squares* s)
     if (!s) return;
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
-    DevBuf* bufs[] = {&s->d_descs, &s->d_masks, &s->d_gray, &s->d_ref, &s->d_mean, &s->d_var, &s->d_stats, &s->d_select, &s->d_coef, &s->d_stage};
+    DevBuf* bufs[] = {&s->d_descs, &s->d_masks, &s->d_gray, &s->d_ref, &s->d_mean, &s->d_var, &s->d_stats, &s->d_select, &s->d_coef, &s->d_stage, &s->d_hough};
     for (auto b : bufs) dev_free(b);
     delete s;
 }
@@ -768,7 +768,7 @@ extern "C" int cbv_squares_hough(cbv_squares* s, const cbv_hough_params* prm, cb
     HoughCfg hc;
     RC(hough_cfg(ctx, prm, s->descs, &hc));
     RC(dev_ensure(ctx, &s->d_hough, sizeof(cbv_hough_result) * CBV_MAX_SQUARES));
-    RC(launch_hough(ctx, (const SquareDesc*)s->d_descs.p, s->n, (const u8*)s->d_gray.p, 0, hc, (cbv_hough_result*)s->d_hough.p, nullptr, 1));
+    RC(launch_hough(ctx, (const SquareDesc*)s->d_descs.p, s->n, (const u8*)s->d_gray.p, 0, hc, (cbv_hough_result*)s->d_hough.p, nullptr, nullptr, 1));
     CBV_HIP(ctx, hipMemcpyAsync(out, s->d_hough.p, sizeof(cbv_hough_result) * s->n, hipMemcpyDeviceToHost, ctx->stream));
     CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return CBV_OK;
@@ -847,6 +847,7 @@ struct cbv_pipeline {
     u8* A[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
     u8* B[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
     DevBuf lane_small[MAX_LANES];
+    DevBuf lane_work[MAX_LANES]; // HoughCircles worklist of the lane's current chunk: count, then frame << 8 | square
     u8* enhanced = nullptr; // [max_frames] when keep_enhanced
     u8* warped = nullptr;   // [max_frames][S][S][3]
     size_t warped_stride = 0;
@@ -887,6 +888,7 @@ extern "C" void cbv_pipeline_destroy(cbv_pipeline* p)
         if (p->A[l]) (void)hipFree(p->A[l]);
         if (p->B[l]) (void)hipFree(p->B[l]);
         dev_free(&p->lane_small[l]);
+        dev_free(&p->lane_work[l]);
         if (p->lane_done[l]) (void)hipEventDestroy(p->lane_done[l]);
         if (p->lane_stream[l]) (void)hipStreamDestroy(p->lane_stream[l]);
     }
@@ -894,7 +896,7 @@ extern "C" void cbv_pipeline_destroy(cbv_pipeline* p)
     if (p->frames) (void)hipFree(p->frames);
     if (p->enhanced) (void)hipFree(p->enhanced);
     if (p->warped) (void)hipFree(p->warped);
-    DevBuf* bufs[] = {&p->d_descs, &p->d_masks, &p->d_gray, &p->d_stats, &p->d_ref, &p->d_state, &p->d_results, &p->d_flags, &p->d_dec, &p->d_noise, &p->d_noise_state, &p->d_coef, &p->d_synth, &p->d_mean, &p->d_var};
+    DevBuf* bufs[] = {&p->d_descs, &p->d_masks, &p->d_gray, &p->d_stats, &p->d_ref, &p->d_state, &p->d_results, &p->d_flags, &p->d_dec, &p->d_noise, &p->d_noise_state, &p->d_coef, &p->d_synth, &p->d_mean, &p->d_var, &p->d_hough};
     for (auto b : bufs) dev_free(b);
     delete p;
 }
@@ -939,6 +941,7 @@ extern "C" int cbv_pipeline_configure(cbv_pipeline* p, const cbv_pipeline_config
         CBV_HIP(ctx, hipMalloc((void**)&p->B[l], p->g.frame_stride * chunk));
         SmallLayout SL;
         RC(small_layout(ctx, &p->lane_small[l], cfg->enhance.tiles_x * cfg->enhance.tiles_y, chunk, &SL));
+        RC(dev_ensure(ctx, &p->lane_work[l], sizeof(u32) * (1 + (size_t)CBV_MAX_SQUARES * chunk)));
         if (l > 0 && !p->lane_stream[l]) CBV_HIP(ctx, hipStreamCreateWithFlags(&p->lane_stream[l], hipStreamNonBlocking));
         if (!p->lane_done[l]) CBV_HIP(ctx, hipEventCreateWithFlags(&p->lane_done[l], hipEventDisableTiming));
     }
@@ -1095,14 +1098,24 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
                                            (u8*)p->d_gray.p + p->plane_total * s0, p->plane_total, b);
         if (rc_all) break;
         u8* dec = (u8*)p->d_dec.p + (size_t)CBV_MAX_SQUARES * s0;
+        u32* work = nullptr;
+        cbv_hough_result* hres = nullptr;
+        if (cfg.use_hough) {
+            work = (u32*)p->lane_work[lane].p;
+            hres = (cbv_hough_result*)p->d_hough.p + (size_t)CBV_MAX_SQUARES * s0;
+            if (hipMemsetAsync(work, 0, sizeof(u32), ctx->stream) != hipSuccess) {
+                rc_all = cbv_fail(ctx, CBV_ERR_HIP, "reset of the HoughCircles worklist failed");
+                break;
+            }
+        }
         rc_all = launch_squares_stats(ctx, (const SquareDesc*)p->d_descs.p, n, (const u8*)p->d_gray.p + p->plane_total * s0, p->plane_total,
                                       nullptr, p->calibrated ? (const float*)p->d_mean.p : nullptr, p->calibrated ? (const float*)p->d_var.p : nullptr,
                                       (const u8*)p->d_masks.p, (float)cfg.z_threshold, (cbv_sq_stats*)p->d_stats.p + (size_t)n * s0, b,
-                                      dec, cfg.use_hough);
+                                      dec, cfg.use_hough, work, hres);
         if (rc_all) break;
         if (cfg.use_hough)
             rc_all = launch_hough(ctx, (const SquareDesc*)p->d_descs.p, n, (const u8*)p->d_gray.p + p->plane_total * s0, p->plane_total,
-                                  p->hough_cfg, (cbv_hough_result*)p->d_hough.p + (size_t)CBV_MAX_SQUARES * s0, dec, b);
+                                  p->hough_cfg, hres, dec, work, b);
     }
     ctx->stream = main_stream;
     if (rc_all) return rc_all;

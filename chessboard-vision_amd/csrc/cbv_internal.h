@@ -187,7 +187,8 @@ int launch_squares_preprocess(cbv_ctx* ctx, const u8* src, size_t src_frame_stri
                               const int* coef_dev, int blur_k, u8* gray, size_t gray_frame_stride, int batch);
 int launch_squares_stats(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, size_t gray_frame_stride,
                          const u8* ref, const float* mean, const float* var, const u8* masks, float z_thresh,
-                         cbv_sq_stats* out, int batch, u8* decisions = nullptr, int want_hough = 0);
+                         cbv_sq_stats* out, int batch, u8* decisions = nullptr, int want_hough = 0, u32* hough_work = nullptr,
+                         cbv_hough_result* hough_out = nullptr);
 
 // HoughCircles per square (k_hough.hip).  off_* / max_* are filled by launch_hough.
 struct HoughCfg {
@@ -198,9 +199,10 @@ struct HoughCfg {
     int gs, mw, mag_bytes; // padded row strides of the gray/map planes (bytes) and the magnitude plane (u16)
     int off_map, off_mag, off_acc, off_centres, off_bins, off_order, max_bins;
 };
-// `decisions` (may be null): squares whose byte lacks bit 4 are skipped; a found circle sets bit 0.
+// `work` (may be null = every square of every frame): work[0] = number of items, work[1 + i] = frame << 8 | square,
+// as k_squares_stats lists them; a found circle sets bit 0 of the square's `decisions` byte.
 int launch_hough(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, size_t gray_frame_stride, HoughCfg cfg,
-                 cbv_hough_result* out, u8* decisions, int batch);
+                 cbv_hough_result* out, u8* decisions, const u32* work, int batch);
 int launch_squares_calibrate(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, float* mean, float* var,
                              float init_var, const u8* select);
 int launch_squares_ema(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, float* mean, float* var,

@@ -70,22 +70,21 @@ __device__ __forceinline__ int hg_sel4(int i, int a, int b, int c, int d) { retu
 
 __global__ __launch_bounds__(HG_NT) void k_hough(const SquareDesc* __restrict__ descs, const u8* __restrict__ gray,
                                                 size_t gray_frame_stride, HoughCfg cfg,
-                                                cbv_hough_result* __restrict__ out, u8* __restrict__ decisions)
+                                                cbv_hough_result* __restrict__ out, u8* __restrict__ decisions,
+                                                const u32* __restrict__ work, int nsq, int total_items)
 {
     extern __shared__ __align__(16) u8 smem[];
     __shared__ int s_cnt[4]; // 0 weak, 1 edges, 2 centres, 3 circles
     __shared__ int s_over;
-    const size_t oi = (size_t)blockIdx.z * CBV_MAX_SQUARES + blockIdx.x;
-    if (decisions && !(decisions[oi] & 16)) { // workgroup-uniform: the statistics already decided this square
-        if (out && threadIdx.x == 0) {
-            cbv_hough_result r;
-            memset(&r, 0, sizeof(r));
-            r.flags = CBV_HOUGH_SKIPPED;
-            out[oi] = r;
-        }
-        return;
-    }
-    const SquareDesc d = descs[blockIdx.x];
+    // Work items: with a worklist (pipeline), work[0] = count and work[1 + i] = frame << 8 | square, filled by
+    // k_squares_stats for the squares whose has_piece the statistics left open; otherwise every (square, frame).
+    // A fixed grid of workgroups strides over the items, so idle workgroups never hold an LDS slot.
+    const int n_items = work ? (int)work[0] : total_items;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int sqi = work ? (int)(work[1 + item] & 255u) : item % nsq;
+    const int fri = work ? (int)(work[1 + item] >> 8) : item / nsq;
+    const size_t oi = (size_t)fri * CBV_MAX_SQUARES + sqi;
+    const SquareDesc d = descs[sqi];
     const int w = d.w, h = d.h, n = w * h;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // LDS planes, sized on the host for the largest square of the set (hough_layout).  Rows are padded so that
@@ -124,7 +123,7 @@ __global__ __launch_bounds__(HG_NT) void k_hough(const SquareDesc* __restrict__ 
 #endif
     HG_TICK();
     // P0: plane (tight, 16-byte aligned and zero padded to 16) -> padded rows; zero the magnitude plane
-    const u32* src = (const u32*)(gray + (size_t)blockIdx.z * gray_frame_stride + d.plane_off);
+    const u32* src = (const u32*)(gray + (size_t)fri * gray_frame_stride + d.plane_off);
     for (int i = tid; i < (n + 3) >> 2; i += HG_NT) {
         const u32 v = src[i];
         int y = __umulhi((u32)(4 * i), inv_w), x = 4 * i - y * w;
@@ -439,7 +438,7 @@ __global__ __launch_bounds__(HG_NT) void k_hough(const SquareDesc* __restrict__ 
         sorted[rank] = ci;
     }
     __syncthreads();
-    if (wave != 0) return;
+    if (wave == 0) {
     float md = (float)(min_dim / 3);
     if (md < dp) md = dp;
     const float md2 = md * md;
@@ -540,6 +539,9 @@ __global__ __launch_bounds__(HG_NT) void k_hough(const SquareDesc* __restrict__ 
             out[oi] = r;
         }
     }
+    } // wave 0
+    __syncthreads(); // LDS is reused by the next item
+    } // items
 }
 
 // LDS layout for squares up to maxw x maxh
@@ -581,7 +583,7 @@ static size_t hough_layout(HoughCfg& cfg)
 }
 
 int launch_hough(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, size_t gray_frame_stride, HoughCfg cfg,
-                 cbv_hough_result* out, u8* decisions, int batch)
+                 cbv_hough_result* out, u8* decisions, const u32* work, int batch)
 {
     if (cfg.maxw < 2 || cfg.maxh < 2 || cfg.maxw > 250 || cfg.maxh > 250)
         return cbv_fail(ctx, CBV_ERR_UNSUPPORTED, "HoughCircles stage: squares must be 2..250 px (got %dx%d)", cfg.maxw, cfg.maxh);
@@ -593,8 +595,14 @@ int launch_hough(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, s
         CBV_HIP(ctx, hipFuncSetAttribute((const void*)k_hough, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = lds;
     }
+    // as many workgroups as the chip holds at once (LDS-limited), striding over the work items
+    const int per_cu = (int)(160 * 1024 / (lds + 1024)) < 2 ? ((int)(160 * 1024 / (lds + 1024)) < 1 ? 1 : (int)(160 * 1024 / (lds + 1024))) : 2;
+    int grid = ctx->num_cus * per_cu;
+    const int total = n * batch;
+    if (grid > total) grid = total;
+    if (grid < 1) grid = 1;
     prof_begin(ctx, CBV_K_HOUGH);
-    hipLaunchKernelGGL(k_hough, dim3(n, 1, batch), dim3(HG_NT), lds, ctx->stream, descs, gray, gray_frame_stride, cfg, out, decisions);
+    hipLaunchKernelGGL(k_hough, dim3(grid), dim3(HG_NT), lds, ctx->stream, descs, gray, gray_frame_stride, cfg, out, decisions, work, n, total);
     prof_end(ctx, CBV_K_HOUGH);
     CBV_HIP(ctx, hipGetLastError());
     return CBV_OK;

@@ -151,7 +151,8 @@ __global__ __launch_bounds__(256) void k_squares_stats(const SquareDesc* __restr
                                                         const u8* __restrict__ ref, const float* __restrict__ mean,
                                                         const float* __restrict__ var, const u8* __restrict__ masks,
                                                         float z_thresh, cbv_sq_stats* __restrict__ out, int nsq,
-                                                        u8* __restrict__ decisions, int want_hough)
+                                                        u8* __restrict__ decisions, int want_hough, u32* __restrict__ hough_work,
+                                                        cbv_hough_result* __restrict__ hough_out)
 {
     __shared__ u32 acc[20];
     __shared__ float zm[4];
@@ -227,7 +228,15 @@ __global__ __launch_bounds__(256) void k_squares_stats(const SquareDesc* __restr
             // statistics-based detectors said no on a non-uniform square; it then sets bit0 itself
             const int dp = d_detect_piece(st);
             u32 dc = dp == 1 ? 1u : 0u;
-            if (want_hough && (dp == 2 || (want_hough == 2 && dp == 1))) dc |= 16u;
+            if (want_hough && (dp == 2 || (want_hough == 2 && dp == 1))) {
+                dc |= 16u;
+                if (hough_work) hough_work[1 + atomicAdd(&hough_work[0], 1u)] = ((u32)blockIdx.z << 8) | blockIdx.x;
+            } else if (want_hough && hough_out) {
+                cbv_hough_result r;
+                memset(&r, 0, sizeof(r));
+                r.flags = CBV_HOUGH_SKIPPED;
+                hough_out[(size_t)blockIdx.z * CBV_MAX_SQUARES + blockIdx.x] = r;
+            }
             if (mean) {
                 const double pct = ((double)st.z_count / (double)st.n) * 100.0; // change_detector.py:139 as a Python float
                 if (!(pct < 5.0)) dc |= 2u | (pct > 75.0 ? 8u : (pct > 15.0 ? 4u : 0u));
@@ -239,11 +248,12 @@ __global__ __launch_bounds__(256) void k_squares_stats(const SquareDesc* __restr
 
 int launch_squares_stats(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, size_t gray_frame_stride,
                          const u8* ref, const float* mean, const float* var, const u8* masks, float z_thresh,
-                         cbv_sq_stats* out, int batch, u8* decisions, int want_hough)
+                         cbv_sq_stats* out, int batch, u8* decisions, int want_hough, u32* hough_work,
+                         cbv_hough_result* hough_out)
 {
     prof_begin(ctx, CBV_K_SQUARES);
     hipLaunchKernelGGL(k_squares_stats, dim3(n, 1, batch), dim3(256), 0, ctx->stream, descs, gray, gray_frame_stride,
-                       ref, mean, var, masks, z_thresh, out, n, decisions, want_hough);
+                       ref, mean, var, masks, z_thresh, out, n, decisions, want_hough, hough_work, hough_out);
     prof_end(ctx, CBV_K_SQUARES);
     CBV_HIP(ctx, hipGetLastError());
     return CBV_OK;

@@ -18,6 +18,9 @@ CALIB_GRID_Y = (0, 80, 158, 235, 311, 388, 465, 542, 620)
 SHIPPED_PROFILE = {"hue_shift": -86, "sat_scale": 0.91, "val_scale": 2.46, "contrast": 1.48,
                    "brightness": -30, "radical_mode": 0, "target_hue": 0, "hue_window": 26}
 
+# piece_detector_settings.json of the reference: min_radius 25, max_radius 55 (percent of the square)
+SHIPPED_DETECTOR = {"min_radius_ratio": 0.25, "max_radius_ratio": 0.55}
+
 # Scene palettes (BGR).  "normal": a well-lit board, used with an empty colour
 # profile.  "dim": an under-exposed camera, the situation the shipped profile
 # (contrast 1.48, brightness -30, val x2.46) was calibrated for.

@@ -1,0 +1,40 @@
+"""Turn the two rocprofv3 counter CSVs of tools/profile_round.sh (--pmc FETCH_SIZE, --pmc WRITE_SIZE; separate
+passes over `bench.py --frames 128 --steps 1 --warmup 1 --lanes 1`) into profiles/pmc_traffic.json:
+HBM bytes per frame and kernel = (2 x FETCH_SIZE + WRITE_SIZE) KiB of the batched dispatches / frames per dispatch
+(gfx950 counts 64 B per 128-B read request; MI355X_MICROARCH.md, HBM section)."""
+import collections
+import csv
+import json
+import sys
+
+fetch_csv, write_csv, frames, chunk = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+
+
+def load(path):
+    per = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+        per[name].append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    return per
+
+
+F, Wr = load(fetch_csv), load(write_csv)
+out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --frames %d --steps 1 "
+               "--warmup 1 --lanes 1` (%d frames per dispatch). HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 counts 64 B per "
+               "128-B read request; WRITE_SIZE exact), both reported in KiB (MI355X_MICROARCH.md, HBM section). Per kernel: the "
+               "dispatches of the largest batch (the chunked launches), averaged." % (frames, chunk),
+       "width": 1920, "height": 1080, "kernels": {}}
+whole = {"k_synth", "k_scan", "k_noise", "k_pack_results"}
+for k in sorted(F):
+    if not k.startswith("k_") or k not in Wr:
+        continue
+    # keep the big dispatches only (single-frame launches of calibration / profile passes are far smaller)
+    fmax = max(v for v, _ in F[k])
+    fsel = [v for v, _ in F[k] if v >= 0.5 * fmax] or [fmax]
+    wmax = max(v for v, _ in Wr[k])
+    wsel = [v for v, _ in Wr[k] if v >= 0.5 * wmax] or [wmax]
+    f_kib, w_kib = sum(fsel) / len(fsel), sum(wsel) / len(wsel)
+    fpd = frames if k in whole else chunk
+    out["kernels"][k] = {"FETCH_SIZE_KiB": round(f_kib, 1), "WRITE_SIZE_KiB": round(w_kib, 1), "frames_per_dispatch": fpd,
+                         "bytes_per_frame": int((2 * f_kib + w_kib) * 1024 / fpd)}
+json.dump(out, sys.stdout, indent=1)
