@@ -229,6 +229,11 @@ def main():
         valu_ops_px = 49 * 7 + 45
         valu_ach = valu_ops_px * w * h * frames_per_launch / (avg_ms * 1e-3) / 1e12 if bl_n else float("nan")
         valu_peak = 256 * 4 * 32 * 2.4e9 / 1e12
+        # issue-clock model from measured per-instruction costs (tools/ubench_pk.hip, clocks per wave64 instruction per
+        # SIMD at 2.4 GHz): per tap and output v_sad_u8 4.62 + v_alignbit 4.79 + v_mul 2.71 + 3 v_fma 9.0 + v_add 2.53
+        # + 0.92 v_cvt_f32_ubyte 4.21; 45 further ops per pixel at ~3
+        issue_clk_px_wave = 49 * (4.62 + 4.79 + 2.71 + 9.0 + 2.53 + 0.92 * 4.58) + 45 * 3.0
+        issue_bound_ms = issue_clk_px_wave * (w * h * frames_per_launch / 64.0) / (256 * 4) / 2.4e9 * 1e3
         out = {
             "metric": "frames/sec enhance->warp->64-sq detect @1080p; % HBM roofline",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -243,7 +248,11 @@ def main():
                          "note": "dominant kernel; VALU-bound stencil (49 taps/px), priced against HBM with its algorithmic bytes 2N; "
                                  "timed live with HIP events in the timed region (%d lanes overlap chunks)" % (args.lanes if args.lanes > 0 else 2),
                          "valu": {"lane_ops_per_px": valu_ops_px, "achieved": round(valu_ach, 2), "peak": round(valu_peak, 1), "unit": "T lane-ops/s",
-                                  "frac": round(valu_ach / valu_peak, 4), "note": "peak = 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz (full-rate ops); v_sad_u8, v_alignbit, v_cvt are half-rate"}},
+                                  "frac": round(valu_ach / valu_peak, 4), "note": "peak = 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz (full-rate ops); v_sad_u8, v_alignbit, v_cvt are half-rate",
+                                  "issue_bound_ms_per_launch": round(issue_bound_ms, 4),
+                                  "issue_frac_live": round(issue_bound_ms / avg_ms, 4) if bl_n else None,
+                                  "issue_frac_alone": round(issue_bound_ms / kernels["k_bilateral"]["avg_ms"], 4) if "k_bilateral" in kernels else None,
+                                  "issue_note": "time the kernel's own instruction mix needs at the measured issue cost of each instruction (tools/ubench_pk.hip) / time taken, live in the timed region (other kernels share the CUs) and alone (single-lane pass)"}},
             "path_roofline": {"alg_bytes_per_frame": path_bytes, "achieved": round(path_bytes * fps / world / 1e9, 2), "peak": HBM_PEAK_GBPS,
                               "unit": "GB/s", "frac": round(path_bytes * fps / world / 1e9 / HBM_PEAK_GBPS, 5)},
             "kernels": kernels, "single_frame_ms": single_ms, "cpu_baseline": cpu, "occupancy_check": bool(occ_ok),
