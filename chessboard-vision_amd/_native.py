@@ -167,6 +167,7 @@ def load():
         "cbv_squares_ema": (i32, [vp, dbl, vp]),
         "cbv_squares_set_ref": (i32, [vp, vp]),
         "cbv_squares_stats": (i32, [vp, i32, i32, dbl, P(SqStats)]),
+        "cbv_canny": (i32, [vp, u8p, i32, i32, i32, i32, dbl, dbl, u8p, i32]),
         "cbv_squares_hough": (i32, [vp, P(HoughParams), P(HoughResult)]),
         "cbv_squares_get": (i32, [vp, i32, i32, vp]),
         "cbv_squares_set": (i32, [vp, i32, i32, vp]),

@@ -442,6 +442,24 @@ extern "C" int cbv_prepare_analysis(cbv_ctx* ctx, const uint8_t* bgr, int w, int
     return CBV_OK;
 }
 
+extern "C" int cbv_canny(cbv_ctx* ctx, const uint8_t* img, int w, int h, int stride, int cn, double threshold1, double threshold2,
+                         uint8_t* edges, int edges_stride)
+{
+    RC(check_img(ctx, img, w, h, stride, cn, "cbv_canny"));
+    if (!edges || (cn != 1 && cn != 3)) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_canny: null output or unsupported channel count");
+    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    RC(upload(ctx, &ctx->in, img, w * cn, h, stride));
+    // cv::Canny: thresholds are ordered, then floored (L1 gradient)
+    double lo = threshold1 < threshold2 ? threshold1 : threshold2, hi = threshold1 < threshold2 ? threshold2 : threshold1;
+    const int low = (int)floor(lo), high = (int)floor(hi);
+    size_t plane = ((size_t)w * h + 255) & ~(size_t)255;
+    RC(dev_ensure(ctx, &ctx->a, plane));
+    RC(launch_canny(ctx, (const u8*)ctx->in.p, w, h, w * cn, cn, low, high, (u8*)ctx->a.p, &ctx->b));
+    CBV_HIP(ctx, hipMemcpy2DAsync(edges, edges_stride, ctx->a.p, w, w, h, hipMemcpyDeviceToHost, ctx->stream));
+    CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CBV_OK;
+}
+
 // enhancement chain on device buffers: src -> (A, B ping-pong) ; result pointer returned.
 // When `fold_norm` the final normalize pass is skipped and the caller applies S.norm_lut downstream.
 static int enhance_dev(cbv_ctx* ctx, const u8* src, u8* A, u8* B, Geom g, const cbv_enhance_params* P, SmallLayout S,

@@ -173,6 +173,8 @@ int launch_threshold(cbv_ctx* ctx, const u8* blur, u8* binary, const u32* aux, i
 int launch_synth(cbv_ctx* ctx, u8* dst, Geom g, const u64* seeds_dev, const double* hinv_dev, const u8* boards_dev,
                  const cbv_scene* scene_dev, int batch);
 
+int launch_canny(cbv_ctx* ctx, const u8* src, int w, int h, int stride, int cn, int low, int high, u8* edges, DevBuf* scratch);
+
 // squares
 struct SquareDesc {
     int w, h;

@@ -31,6 +31,34 @@ class GridExtractor:
         return list(_cells_linear(rows, cols))
 
 
+def canny(img, threshold1, threshold2):
+    """cv2.Canny(img, threshold1, threshold2) on the GPU; BGR input is converted to gray first."""
+    from . import _native as N
+    a = np.asarray(img)
+    if a.dtype != np.uint8 or a.ndim not in (2, 3) or (a.ndim == 3 and a.shape[2] != 3):
+        raise ValueError("canny expects an HxW or HxWx3 uint8 image")
+    if a.strides[-1] != 1 or (a.ndim == 3 and a.strides[1] != 3):
+        a = np.ascontiguousarray(a)
+    ctx = N.context()
+    out = np.empty(a.shape[:2], np.uint8)
+    ctx.check(ctx.lib.cbv_canny(ctx.h, a.ctypes.data, a.shape[1], a.shape[0], a.strides[0], 3 if a.ndim == 3 else 1,
+                                float(threshold1), float(threshold2), out.ctypes.data, out.strides[0]))
+    return out
+
+
+def _lines_from_projection(proj, length):
+    """9 line positions: the borders plus, per inner line, the first maximum of `proj` inside its search window."""
+    step = length / 8.0
+    radius = int(step * 0.3)
+    lines = [0]
+    for i in range(1, 8):
+        nominal = int(i * step)
+        lo, hi = max(0, nominal - radius), min(length, nominal + radius)
+        lines.append(lo + int(np.argmax(proj[lo:hi])) if hi > lo else nominal)
+    lines.append(length)
+    return lines
+
+
 class SmartGridExtractor:
     def __init__(self, debug=False):
         self.grid_lines_x = None
@@ -38,8 +66,17 @@ class SmartGridExtractor:
         self.debug = debug
 
     def refine_grid(self, img_warped):
-        raise NotImplementedError("SmartGridExtractor.refine_grid is calibration-time code (Canny projections) and "
-                                  "is outside the MI355X hot path; set grid_lines_x / grid_lines_y from calibration.json")
+        """grid_extractor.py:66-121: Canny(gray, 50, 150) on the warped board, edge counts per column / row, and
+        for each of the 7 inner lines the strongest count within +-30 % of a square around its nominal place.
+        Canny runs on the GPU (cbv_canny; restated from the published algorithm, parity unpinned)."""
+        h, w = img_warped.shape[:2]
+        edges = canny(img_warped, 50, 150)
+        self.grid_lines_x = _lines_from_projection(edges.sum(axis=0, dtype=np.uint64), w)
+        self.grid_lines_y = _lines_from_projection(edges.sum(axis=1, dtype=np.uint64), h)
+        if self.debug:
+            print(f"Refined X: {self.grid_lines_x}")
+            print(f"Refined Y: {self.grid_lines_y}")
+        return self.grid_lines_x, self.grid_lines_y
 
     def split_board(self, img_warped):
         if self.grid_lines_x is None or self.grid_lines_y is None:

@@ -220,6 +220,12 @@ CBV_API int cbv_squares_get(cbv_squares* sq, int which, int index, void* out);
 CBV_API int cbv_squares_set(cbv_squares* sq, int which, int index, const void* in);
 CBV_API int cbv_squares_geometry(cbv_squares* sq, int index, int* w, int* h);
 
+/* cv2.Canny(img, threshold1, threshold2) with the default aperture 3 and L1 gradient, as
+ * SmartGridExtractor.refine_grid (grid_extractor.py:66-121) uses it on the warped board at calibration time
+ * (SURVEY §8 f3).  img: 1 or 3 channels (BGR is converted with BGR2GRAY first); edges: 0 / 255. */
+CBV_API int cbv_canny(cbv_ctx* ctx, const uint8_t* img, int w, int h, int stride, int cn, double threshold1,
+                      double threshold2, uint8_t* edges, int edges_stride);
+
 /* ------------------------------------------------------------------ */
 /* device-resident batched pipeline: enhance -> warp -> 64-square detect */
 /* over frames that stay in HBM (bench configs C2..C5)                  */

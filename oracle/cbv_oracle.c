@@ -1356,3 +1356,15 @@ ORC_API int orc_hough_circles(const u8* gray, int w, int h, double dp_d, double 
     free(edges);
     return ncirc;
 }
+
+/* cv2.Canny(gray, t1, t2) (grid_extractor.py:75): aperture 3, L1 gradient; thresholds ordered and floored. */
+ORC_API void orc_canny_u8(const u8* gray, int w, int h, double t1, double t2, u8* edges)
+{
+    short* dx = (short*)malloc(sizeof(short) * (size_t)w * h);
+    short* dy = (short*)malloc(sizeof(short) * (size_t)w * h);
+    double lo = t1 < t2 ? t1 : t2, hi = t1 < t2 ? t2 : t1;
+    orc_sobel3(gray, w, h, dx, dy);
+    orc_canny(dx, dy, w, h, (int)floor(lo), (int)floor(hi), edges);
+    free(dx);
+    free(dy);
+}

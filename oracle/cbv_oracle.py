@@ -319,3 +319,12 @@ def hough_circles(gray, dp=1.2, min_dist=25, param1=100, param2=25, min_radius=1
                                 int(min_radius), int(max_radius), out, 64, _p(edges))
     res = [(out[i].x, out[i].y, out[i].r, out[i].votes) for i in range(min(n, 64))]
     return (res, edges) if return_edges else res
+
+
+def canny(gray, t1, t2):
+    """cv2.Canny(gray, t1, t2) restated (aperture 3, L1 gradient); parity unpinned."""
+    gray = np.ascontiguousarray(_u8(gray))
+    h, w = gray.shape
+    edges = np.empty((h, w), np.uint8)
+    lib().orc_canny_u8(_p(gray), w, h, C.c_double(t1), C.c_double(t2), _p(edges))
+    return edges

@@ -374,3 +374,41 @@ def test_detect_piece_reports_hough_method(gpu_ctx, oracle):
     from ref_logic import detect_circle_unified
     assert det._detect_circle_unified(gray) == detect_circle_unified(gray)[:4]
 
+
+
+@pytest.mark.parametrize("shape,t", [((620, 620), (50, 150)), ((131, 257), (30, 100)), ((5, 7), (50, 150)), ((64, 64), (150, 50))])
+def test_canny_matches_oracle(gpu_ctx, oracle, shape, t):
+    """cbv_canny vs the oracle's cv2.Canny restatement: textured images with long weak chains that cross the
+    hysteresis tiles, sizes that are no multiple of the tile, swapped thresholds.  PARITY UNPINNED against cv2."""
+    from chessboard_vision_amd.grid_extractor import canny
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    h, w = shape
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = (96 + 60 * np.sin(xx / 9.0) * np.cos(yy / 13.0) + 50 * ((xx // 40 + yy // 40) % 2)).astype(np.float64)
+    img = np.clip(img + rng.normal(0, 6, img.shape), 0, 255).astype(np.uint8)
+    gray = oracle.gaussian_blur(img, 5) if min(h, w) >= 5 else img
+    got, want = canny(gray, *t), oracle.canny(gray, *t)
+    assert np.array_equal(got, want), (shape, int((got != want).sum()))
+    if min(shape) > 60:
+        assert 0 < int((want > 0).sum()) < want.size // 2
+
+
+def test_refine_grid_matches_oracle_restatement(gpu_ctx, oracle):
+    """SmartGridExtractor.refine_grid (grid_extractor.py:66-121) on a warped synthetic board: same lines as the
+    reference's numpy logic evaluated on the oracle's Canny, and close to the true 77.5-px pitch."""
+    from chessboard_vision_amd.grid_extractor import SmartGridExtractor
+    f = oracle_frame(1920, 1080, "normal", frame_idx=0)
+    warped, _, _ = oracle.warp_image(f, S.scaled_corners(1920, 1080))
+    gx, gy = SmartGridExtractor().refine_grid(warped)
+    edges = oracle.canny(oracle.bgr2gray(warped), 50, 150)
+
+    def ref_lines(proj, length):  # the reference's find_internal_lines, restated
+        step, lines = length / 8.0, [0]
+        for i in range(1, 8):
+            c, r = int(i * step), int(step * 0.3)
+            s, e = max(0, c - r), min(length, c + r)
+            lines.append(s + int(np.argmax(proj[s:e])) if e > s else c)
+        return lines + [length]
+    assert gx == ref_lines(np.sum(edges, axis=0), 620) and gy == ref_lines(np.sum(edges, axis=1), 620)
+    assert all(abs(v - 77.5 * i) <= 3 for i, v in enumerate(gx)) and all(abs(v - 77.5 * i) <= 3 for i, v in enumerate(gy))
+    assert len(SmartGridExtractor().split_board(warped)) == 64
