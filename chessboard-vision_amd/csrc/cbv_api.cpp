@@ -887,7 +887,7 @@ extern "C" int cbv_pipeline_create(cbv_ctx* ctx, int w, int h, int max_frames, c
     p->h = h;
     p->max_frames = max_frames;
     p->g = tight_geom(w, h);
-    hipError_t e = hipMalloc((void**)&p->frames, p->g.frame_stride * max_frames);
+    hipError_t e = hipMalloc((void**)&p->frames, p->g.frame_stride * max_frames + 256);
     if (e != hipSuccess) {
         delete p;
         return cbv_fail(ctx, CBV_ERR_HIP, "hipMalloc of %zu bytes for the frame ring failed: %s", p->g.frame_stride * max_frames, hipGetErrorString(e));
@@ -955,8 +955,8 @@ extern "C" int cbv_pipeline_configure(cbv_pipeline* p, const cbv_pipeline_config
     p->warped = p->enhanced = nullptr;
     if (!p->start_ev) CBV_HIP(ctx, hipEventCreateWithFlags(&p->start_ev, hipEventDisableTiming));
     for (int l = 0; l < lanes; l++) {
-        CBV_HIP(ctx, hipMalloc((void**)&p->A[l], p->g.frame_stride * chunk));
-        CBV_HIP(ctx, hipMalloc((void**)&p->B[l], p->g.frame_stride * chunk));
+        CBV_HIP(ctx, hipMalloc((void**)&p->A[l], p->g.frame_stride * chunk + 256));
+        CBV_HIP(ctx, hipMalloc((void**)&p->B[l], p->g.frame_stride * chunk + 256));
         SmallLayout SL;
         RC(small_layout(ctx, &p->lane_small[l], cfg->enhance.tiles_x * cfg->enhance.tiles_y, chunk, &SL));
         RC(dev_ensure(ctx, &p->lane_work[l], sizeof(u32) * (1 + (size_t)CBV_MAX_SQUARES * chunk)));
@@ -964,7 +964,7 @@ extern "C" int cbv_pipeline_configure(cbv_pipeline* p, const cbv_pipeline_config
         if (!p->lane_done[l]) CBV_HIP(ctx, hipEventCreateWithFlags(&p->lane_done[l], hipEventDisableTiming));
     }
     CBV_HIP(ctx, hipMalloc((void**)&p->warped, p->warped_stride * p->max_frames));
-    if (p->keep_enhanced) CBV_HIP(ctx, hipMalloc((void**)&p->enhanced, p->g.frame_stride * p->max_frames));
+    if (p->keep_enhanced) CBV_HIP(ctx, hipMalloc((void**)&p->enhanced, p->g.frame_stride * p->max_frames + 256));
     // squares
     const int n = cfg->n_rois;
     p->descs.assign(n, SquareDesc());

@@ -590,11 +590,8 @@ int launch_hough(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, s
     const size_t lds = hough_layout(cfg);
     if (lds > 150 * 1024)
         return cbv_fail(ctx, CBV_ERR_UNSUPPORTED, "HoughCircles stage: %dx%d squares do not fit the LDS layout", cfg.maxw, cfg.maxh);
-    static size_t attr_set = 0;
-    if (lds > 64 * 1024 && lds > attr_set) {
+    if (lds > 64 * 1024) // per device and cheap: no caching across contexts
         CBV_HIP(ctx, hipFuncSetAttribute((const void*)k_hough, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = lds;
-    }
     // as many workgroups as the chip holds at once (LDS-limited), striding over the work items
     const int per_cu = (int)(160 * 1024 / (lds + 1024)) < 2 ? ((int)(160 * 1024 / (lds + 1024)) < 1 ? 1 : (int)(160 * 1024 / (lds + 1024))) : 2;
     int grid = ctx->num_cus * per_cu;

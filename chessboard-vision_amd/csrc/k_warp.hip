@@ -48,19 +48,36 @@ __global__ __launch_bounds__(256) void k_warp(const u8* __restrict__ src, Geom g
         const bool y0in = sy >= 0 && sy < g.h, y1in = sy + 1 >= 0 && sy + 1 < g.h;
         const u8* p00 = sf + (size_t)sy * g.stride + (size_t)sx * 3;
         const u8* p10 = p00 + g.stride;
+        int v[4][3]; // taps 00, 01, 10, 11
+        if (x0in && x1in && y0in && y1in) {
+            // interior: the two taps of a row are 6 contiguous bytes -> ONE unaligned 8-byte load per row instead of
+            // six byte loads (the gather is bound by the number of memory instructions, not by bytes); the two bytes
+            // read past the second tap stay inside the buffer (callers keep >= 8 bytes of slack behind the last frame)
+            u64 a, b;
+            __builtin_memcpy(&a, p00, 8);
+            __builtin_memcpy(&b, p10, 8);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                v[0][k] = (int)((a >> (8 * k)) & 255);
+                v[1][k] = (int)((a >> (8 * (3 + k))) & 255);
+                v[2][k] = (int)((b >> (8 * k)) & 255);
+                v[3][k] = (int)((b >> (8 * (3 + k))) & 255);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                v[0][k] = (x0in && y0in) ? p00[k] : -1;
+                v[1][k] = (x1in && y0in) ? p00[3 + k] : -1;
+                v[2][k] = (x0in && y1in) ? p10[k] : -1;
+                v[3][k] = (x1in && y1in) ? p10[3 + k] : -1;
+            }
+        }
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            int v00 = (x0in && y0in) ? p00[k] : 0;
-            int v01 = (x1in && y0in) ? p00[3 + k] : 0;
-            int v10 = (x0in && y1in) ? p10[k] : 0;
-            int v11 = (x1in && y1in) ? p10[3 + k] : 0;
-            if (use_lut) {
-                v00 = (x0in && y0in) ? lut[v00] : 0;
-                v01 = (x1in && y0in) ? lut[v01] : 0;
-                v10 = (x0in && y1in) ? lut[v10] : 0;
-                v11 = (x1in && y1in) ? lut[v11] : 0;
-            }
-            o[k] = d_sat8((v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11 + (1 << 14)) >> 15);
+            int t[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) t[q] = v[q][k] < 0 ? 0 : (use_lut ? (int)lut[v[q][k]] : v[q][k]); // border taps are 0
+            o[k] = d_sat8((t[0] * w00 + t[1] * w01 + t[2] * w10 + t[3] * w11 + (1 << 14)) >> 15);
         }
     }
     const int ox = rot180 ? dw - 1 - dx : dx, oy = rot180 ? dh - 1 - dy : dy;
