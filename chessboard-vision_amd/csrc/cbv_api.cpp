@@ -874,6 +874,7 @@ struct cbv_pipeline {
     bool calibrated = false;
     std::vector<SquareDesc> descs;
     size_t plane_total = 0;
+    int max_px = 0; // pixels of the largest square
     bool keep_enhanced = false;
 };
 
@@ -984,6 +985,8 @@ extern "C" int cbv_pipeline_configure(cbv_pipeline* p, const cbv_pipeline_config
         off += ((size_t)r.w * r.h + 15) & ~(size_t)15;
     }
     p->plane_total = off;
+    p->max_px = 0;
+    for (int i = 0; i < n; i++) p->max_px = std::max(p->max_px, p->descs[i].w * p->descs[i].h);
     std::vector<u8> masks(off, 0);
     for (int i = 0; i < n; i++) build_piece_mask(p->descs[i].w, p->descs[i].h, masks.data() + p->descs[i].mask_off);
     RC(dev_ensure(ctx, &p->d_descs, sizeof(SquareDesc) * n));
@@ -1113,7 +1116,7 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
         }
         if (rc_all) break;
         rc_all = launch_squares_preprocess(ctx, wdst, p->warped_stride, (const SquareDesc*)p->d_descs.p, n, (const int*)p->d_coef.p, 5,
-                                           (u8*)p->d_gray.p + p->plane_total * s0, p->plane_total, b);
+                                           (u8*)p->d_gray.p + p->plane_total * s0, p->plane_total, b, p->max_px);
         if (rc_all) break;
         u8* dec = (u8*)p->d_dec.p + (size_t)CBV_MAX_SQUARES * s0;
         u32* work = nullptr;

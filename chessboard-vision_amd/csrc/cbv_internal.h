@@ -186,7 +186,7 @@ struct SquareDesc {
     int pad;
 };
 int launch_squares_preprocess(cbv_ctx* ctx, const u8* src, size_t src_frame_stride, const SquareDesc* descs, int n,
-                              const int* coef_dev, int blur_k, u8* gray, size_t gray_frame_stride, int batch);
+                              const int* coef_dev, int blur_k, u8* gray, size_t gray_frame_stride, int batch, int max_px = 0);
 int launch_squares_stats(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, size_t gray_frame_stride,
                          const u8* ref, const float* mean, const float* var, const u8* masks, float z_thresh,
                          cbv_sq_stats* out, int batch, u8* decisions = nullptr, int want_hough = 0, u32* hough_work = nullptr,

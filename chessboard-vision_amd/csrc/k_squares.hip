@@ -67,9 +67,23 @@ __global__ __launch_bounds__(256) void k_squares_preprocess5(const u8* __restric
     const u8* s = src + (size_t)blockIdx.z * src_frame_stride + d.src_off;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     if (d.cn == 3) {
-        for (int y = ty; y < h; y += 16) {
-            const u8* row = s + (size_t)y * d.stride;
-            for (int x = tx; x < w; x += 16) g[y * w + x] = (u8)d_gray(row[3 * x], row[3 * x + 1], row[3 * x + 2]);
+        // four pixels (12 bytes, any alignment) per lane and load instruction: the ROI read is bound by the number
+        // of memory instructions, not by bytes
+        const int ngx = (w + 3) >> 2;
+        for (int t = threadIdx.x; t < ngx * h; t += 256) {
+            const int y = t / ngx, x0 = (t - y * ngx) << 2;
+            const u8* p = s + (size_t)y * d.stride + 3 * x0;
+            u8* o = g + y * w + x0;
+            if (x0 + 3 < w) {
+                u32 v[3];
+                __builtin_memcpy(v, p, 12);
+                o[0] = (u8)d_gray(v[0] & 255, (v[0] >> 8) & 255, (v[0] >> 16) & 255);
+                o[1] = (u8)d_gray(v[0] >> 24, v[1] & 255, (v[1] >> 8) & 255);
+                o[2] = (u8)d_gray((v[1] >> 16) & 255, v[1] >> 24, v[2] & 255);
+                o[3] = (u8)d_gray((v[2] >> 8) & 255, (v[2] >> 16) & 255, v[2] >> 24);
+            } else {
+                for (int k = 0; x0 + k < w; k++) o[k] = (u8)d_gray(p[3 * k], p[3 * k + 1], p[3 * k + 2]);
+            }
         }
     } else {
         for (int y = ty; y < h; y += 16)
@@ -95,9 +109,12 @@ __global__ __launch_bounds__(256) void k_squares_preprocess5(const u8* __restric
 }
 
 int launch_squares_preprocess(cbv_ctx* ctx, const u8* src, size_t src_frame_stride, const SquareDesc* descs, int n,
-                              const int* coef_dev, int blur_k, u8* gray, size_t gray_frame_stride, int batch)
+                              const int* coef_dev, int blur_k, u8* gray, size_t gray_frame_stride, int batch, int max_px)
 {
-    size_t lds = (size_t)((CBV_MAX_SQUARE_DIM * CBV_MAX_SQUARE_DIM + 15) & ~15) + 2 * CBV_MAX_SQUARE_DIM * CBV_MAX_SQUARE_DIM;
+    // LDS by the largest square of the set (u8 gray + u16 horizontal pass), not by the largest square allowed:
+    // 18 KB instead of 48 KB for 77 x 77 squares, i.e. 8 instead of 3 workgroups a CU
+    if (max_px <= 0 || max_px > CBV_MAX_SQUARE_DIM * CBV_MAX_SQUARE_DIM) max_px = CBV_MAX_SQUARE_DIM * CBV_MAX_SQUARE_DIM;
+    size_t lds = (size_t)((max_px + 15) & ~15) + 2 * (size_t)max_px;
     prof_begin(ctx, CBV_K_SQUARES);
     if (blur_k == 5)
         hipLaunchKernelGGL(k_squares_preprocess5, dim3(n, 1, batch), dim3(256), lds, ctx->stream, src, src_frame_stride, descs,
