@@ -60,6 +60,50 @@ __global__ __launch_bounds__(1024) void k(float* out, float seed)
 #pragma unroll
             for (int i = 0; i < 16; i++) asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc[i]) : "v"(w));
         }
+        if (OP == 10) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(ua[i]) : "v"(ua[(i + 5) & 15]));
+        }
+        if (OP == 11) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) asm volatile("v_pk_mad_u16 %0, %0, %1, %2" : "+v"(ua[i]) : "v"(ua[(i + 5) & 15]), "v"(ua[(i + 9) & 15]));
+        }
+        if (OP == 12) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(ua[i]) : "v"(ua[(i + 5) & 15]));
+        }
+        if (OP == 13) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) asm volatile("v_and_b32 %0, %0, %1" : "+v"(ua[i]) : "v"(ua[(i + 5) & 15]));
+        }
+        if (OP == 14) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(ua[i]) : "v"(ua[(i + 5) & 15]), "v"(ua[(i + 9) & 15]));
+        }
+        if (OP == 15) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) asm volatile("v_lshrrev_b32 %0, 8, %0" : "+v"(ua[i]));
+        }
+        if (OP == 16) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) asm volatile("v_cvt_pk_u8_f32 %0, %1, 1, %0" : "+v"(ua[i]) : "v"(acc[i]));
+        }
+        if (OP == 17) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) asm volatile("v_bfe_u32 %0, %0, 8, 8" : "+v"(ua[i]));
+        }
+        if (OP == 18) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) asm volatile("v_min_u32 %0, %0, %1" : "+v"(ua[i]) : "v"(ua[(i + 5) & 15]));
+        }
+        if (OP == 19) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) asm volatile("v_pk_mul_lo_u16 %0, %0, %1" : "+v"(ua[i]) : "v"(ua[(i + 5) & 15]));
+        }
+        if (OP == 20) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) asm volatile("v_pk_sub_i16 %0, %0, %1" : "+v"(ua[i]) : "v"(ua[(i + 5) & 15]));
+        }
     }
     float s = 0;
     unsigned u = 0;
@@ -102,5 +146,16 @@ int main()
     run<7>("16 x v_mul_f32", d, 16, 16);
     run<8>("16 x v_lshl_add_u32", d, 16, 16);
     run<9>("16 x v_add_f32", d, 16, 16);
+    run<10>("16 x v_pk_add_u16", d, 16, 32);
+    run<11>("16 x v_pk_mad_u16", d, 16, 32);
+    run<12>("16 x v_pk_max_i16", d, 16, 32);
+    run<13>("16 x v_and_b32", d, 16, 16);
+    run<14>("16 x v_perm_b32", d, 16, 16);
+    run<15>("16 x v_lshrrev_b32", d, 16, 16);
+    run<16>("16 x v_cvt_pk_u8_f32", d, 16, 16);
+    run<17>("16 x v_bfe_u32", d, 16, 16);
+    run<18>("16 x v_min_u32", d, 16, 16);
+    run<19>("16 x v_pk_mul_lo_u16", d, 16, 32);
+    run<20>("16 x v_pk_sub_i16", d, 16, 32);
     return 0;
 }
