@@ -874,6 +874,17 @@ struct cbv_pipeline {
     bool calibrated = false;
     std::vector<SquareDesc> descs;
     size_t plane_total = 0;
+    // ingest: pinned host mirror of the frame ring, filled by the capture side and copied on its own stream
+    u8* host_ring = nullptr;
+    hipStream_t copy_stream = nullptr;
+    struct CopyRec {
+        int s0, cnt;
+        hipEvent_t ev;
+        bool pending;
+    };
+    std::vector<CopyRec> copies;
+    hipEvent_t run_done = nullptr;
+    int last_run_s0 = 0, last_run_cnt = 0;
     int max_px = 0; // pixels of the largest square
     bool keep_enhanced = false;
 };
@@ -912,6 +923,13 @@ extern "C" void cbv_pipeline_destroy(cbv_pipeline* p)
         if (p->lane_stream[l]) (void)hipStreamDestroy(p->lane_stream[l]);
     }
     if (p->start_ev) (void)hipEventDestroy(p->start_ev);
+    if (p->copy_stream) {
+        (void)hipStreamSynchronize(p->copy_stream);
+        (void)hipStreamDestroy(p->copy_stream);
+    }
+    for (auto& c : p->copies) (void)hipEventDestroy(c.ev);
+    if (p->run_done) (void)hipEventDestroy(p->run_done);
+    if (p->host_ring) (void)hipHostFree(p->host_ring);
     if (p->frames) (void)hipFree(p->frames);
     if (p->enhanced) (void)hipFree(p->enhanced);
     if (p->warped) (void)hipFree(p->warped);
@@ -1054,6 +1072,54 @@ extern "C" int cbv_pipeline_upload(cbv_pipeline* p, int slot, const uint8_t* bgr
     return CBV_OK;
 }
 
+extern "C" uint8_t* cbv_pipeline_host_ring(cbv_pipeline* p)
+{
+    if (!p) return nullptr;
+    cbv_ctx* ctx = p->ctx;
+    if (!p->host_ring) {
+        if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+        if (hipHostMalloc((void**)&p->host_ring, p->g.frame_stride * p->max_frames, hipHostMallocDefault) != hipSuccess) {
+            cbv_fail(ctx, CBV_ERR_HIP, "pinned host ring of %zu bytes could not be allocated", p->g.frame_stride * p->max_frames);
+            p->host_ring = nullptr;
+        }
+    }
+    return p->host_ring;
+}
+
+static bool ranges_overlap(int a0, int an, int b0, int bn) { return a0 < b0 + bn && b0 < a0 + an; }
+
+extern "C" int cbv_pipeline_submit(cbv_pipeline* p, int slot0, int count)
+{
+    if (!p) return CBV_ERR_ARG;
+    cbv_ctx* ctx = p->ctx;
+    if (slot0 < 0 || count <= 0 || slot0 + count > p->max_frames) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_pipeline_submit: bad slot range");
+    if (!p->host_ring) return cbv_fail(ctx, CBV_ERR_STATE, "cbv_pipeline_submit: cbv_pipeline_host_ring() was never called");
+    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    if (!p->copy_stream) CBV_HIP(ctx, hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
+    // do not overwrite device slots a run that is still in flight reads
+    if (p->run_done && ranges_overlap(slot0, count, p->last_run_s0, p->last_run_cnt))
+        CBV_HIP(ctx, hipStreamWaitEvent(p->copy_stream, p->run_done, 0));
+    CBV_HIP(ctx, hipMemcpyAsync(p->frames + p->g.frame_stride * slot0, p->host_ring + p->g.frame_stride * slot0,
+                                p->g.frame_stride * count, hipMemcpyHostToDevice, p->copy_stream));
+    cbv_pipeline::CopyRec* rec = nullptr;
+    for (auto& c : p->copies)
+        if (!c.pending) {
+            rec = &c;
+            break;
+        }
+    if (!rec) {
+        cbv_pipeline::CopyRec c{0, 0, nullptr, false};
+        CBV_HIP(ctx, hipEventCreateWithFlags(&c.ev, hipEventDisableTiming));
+        p->copies.push_back(c);
+        rec = &p->copies.back();
+    }
+    rec->s0 = slot0;
+    rec->cnt = count;
+    rec->pending = true;
+    CBV_HIP(ctx, hipEventRecord(rec->ev, p->copy_stream));
+    return CBV_OK;
+}
+
 extern "C" int cbv_pipeline_synth(cbv_pipeline* p, int slot0, int count, const uint64_t* seeds, const double* Hinv9,
                                   const uint8_t* boards, const cbv_scene* scene)
 {
@@ -1088,6 +1154,11 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
     // Lane 0 is the context's stream; lanes 1.. are worker streams forked from it and joined before
     // the temporal scan (which needs every frame's statistics, in order).
     hipStream_t main_stream = ctx->stream;
+    for (auto& c : p->copies) // ingest copies of these slots must have landed
+        if (c.pending && ranges_overlap(slot0, count, c.s0, c.cnt)) {
+            CBV_HIP(ctx, hipStreamWaitEvent(main_stream, c.ev, 0));
+            c.pending = false;
+        }
     if (p->n_lanes > 1) {
         CBV_HIP(ctx, hipEventRecord(p->start_ev, main_stream));
         for (int l = 1; l < p->n_lanes; l++) CBV_HIP(ctx, hipStreamWaitEvent(p->lane_stream[l], p->start_ev, 0));
@@ -1162,6 +1233,12 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
     // NoiseHandler on the frames' visual_changes sets (game_session.py:165)
     RC(launch_noise(ctx, &((const cbv_frame_result*)p->d_results.p + slot0)->visual_changes, sizeof(cbv_frame_result) / 8, count,
                     (cbv_noise_state*)p->d_noise_state.p, (cbv_noise_result*)p->d_noise.p + slot0));
+    if (p->host_ring) { // lets a later cbv_pipeline_submit know when these slots may be overwritten
+        if (!p->run_done) CBV_HIP(ctx, hipEventCreateWithFlags(&p->run_done, hipEventDisableTiming));
+        CBV_HIP(ctx, hipEventRecord(p->run_done, main_stream));
+        p->last_run_s0 = slot0;
+        p->last_run_cnt = count;
+    }
     return CBV_OK;
 }
 

@@ -92,6 +92,21 @@ class BoardPipeline:
         assert f.shape[:2] == (self.h, self.w)
         self.ctx.check(self.ctx.lib.cbv_pipeline_upload(self.h_, slot, N.ptr(f), f.strides[0]))
 
+    def host_ring(self):
+        """Pinned host mirror of the frame ring as a numpy array [max_frames, h, w, 3]: the capture side writes
+        frames here, `submit` copies them to the GPU asynchronously."""
+        ptr = self.ctx.lib.cbv_pipeline_host_ring(self.h_)
+        if not ptr:
+            raise RuntimeError(self.ctx.lib.cbv_last_error(self.ctx.h).decode())
+        fs = (self.w * self.h * 3 + 255) & ~255  # frames are 256-byte aligned in both rings
+        buf = (C.c_uint8 * (fs * self.max_frames)).from_address(ptr)
+        flat = np.frombuffer(buf, dtype=np.uint8)
+        return np.lib.stride_tricks.as_strided(flat, shape=(self.max_frames, self.h, self.w, 3), strides=(fs, self.w * 3, 3, 1))
+
+    def submit(self, slot0, count):
+        """Enqueue host ring -> device ring for the slots; run() of those slots waits for the copy."""
+        self.ctx.check(self.ctx.lib.cbv_pipeline_submit(self.h_, slot0, count))
+
     def synth(self, slot0, count, stream_id=0, frame0=0, scene="normal", frames_per_ply=32, points=None):
         """Fill slots with synthetic frames of stream `stream_id`, frame indices
         frame0.. (scripted game, one ply every `frames_per_ply` frames)."""

@@ -291,3 +291,44 @@ def test_pipeline_occupancy_drives_game_state(gpu_ctx):
                                       "f1e1", "b7b5", "a4b3", "d7d6", "c2c3", "e8g8"]
     assert [s for _, s in played].count("castling_confirmed") == 2
     assert gs.get_fen() == "r1bq1rk1/2p1bppp/p1np1n2/1p2p3/4P3/1BP2N2/PP1P1PPP/RNBQR1K1 w - - 1 9"
+
+
+def test_ingest_ring_submit_run_overlap(gpu_ctx, oracle):
+    """Ingest front end: frames written into the pinned host ring, copied asynchronously (submit) while the other
+    half of the ring is processed (run); results equal those of synchronous uploads, in any interleaving."""
+    from chessboard_vision_amd.stream import BoardPipeline
+    w, h, half = 322, 241, 4  # odd size: frame stride is padded
+    n = 2 * half
+    pts = S.scaled_corners(w, h)
+    frames = [oracle_frame(w, h, "normal", frame_idx=i, frames_per_ply=2) for i in range(3 * half)]
+    ref = BoardPipeline(w, h, n)
+    ref.configure(pts, profile={}, chunk=4)
+    a = BoardPipeline(w, h, n)
+    a.configure(pts, profile={}, chunk=4)
+    ring = a.host_ring()
+    assert ring.shape == (n, h, w, 3)
+    want, got = [], []
+    # batches of `half` frames alternate between the two halves of the ring
+    batches = [frames[0:half], frames[half:2 * half], frames[2 * half:3 * half]]
+    for b, fr in enumerate(batches):
+        s0 = (b % 2) * half
+        for i, f in enumerate(fr):
+            ref.upload(s0 + i, f)
+        ref.run(s0, half)
+        want += [(r.raw_occupied, r.stable_occupied, r.visual_changes) for r in ref.results(s0, half)]
+    ring[0:half] = np.stack(batches[0])
+    a.submit(0, half)
+    for b in range(3):
+        s0 = (b % 2) * half
+        if b + 1 < 3:  # next batch goes to the other half while this one is processed
+            o0 = ((b + 1) % 2) * half
+            ring[o0:o0 + half] = np.stack(batches[b + 1])   # safe: that half's previous run was collected below
+            a.submit(o0, half)
+        a.run(s0, half)
+        got += [(r.raw_occupied, r.stable_occupied, r.visual_changes) for r in a.results(s0, half)]
+        assert np.array_equal(a.download(0, s0 + 1), batches[b][1])
+    assert got == want
+    with pytest.raises(RuntimeError):
+        a.submit(n - 1, 2)
+    with pytest.raises(RuntimeError):
+        ref.submit(0, 1)  # host ring never requested
