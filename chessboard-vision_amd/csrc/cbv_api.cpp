@@ -885,9 +885,26 @@ struct cbv_pipeline {
     std::vector<CopyRec> copies;
     hipEvent_t run_done = nullptr;
     int last_run_s0 = 0, last_run_cnt = 0;
+    // The temporal scan (+ NoiseHandler) of a run goes to its own stream behind the lanes' events, so the next run's
+    // enhancement of OTHER slots overlaps it; scans of successive runs stay ordered on that stream.
+    hipStream_t scan_stream = nullptr;
+    hipEvent_t scan_done = nullptr, main_done = nullptr;
+    bool scan_pending = false;
+    int scan_s0 = 0, scan_cnt = 0;
     int max_px = 0; // pixels of the largest square
     bool keep_enhanced = false;
 };
+
+// make the context's stream wait for everything the last run enqueued (lanes and scan)
+static int join_scan(cbv_pipeline* p)
+{
+    cbv_ctx* ctx = p->ctx;
+    if (p->scan_pending) {
+        CBV_HIP(ctx, hipStreamWaitEvent(ctx->stream, p->scan_done, 0));
+        p->scan_pending = false;
+    }
+    return CBV_OK;
+}
 
 extern "C" int cbv_pipeline_create(cbv_ctx* ctx, int w, int h, int max_frames, cbv_pipeline** out)
 {
@@ -923,6 +940,12 @@ extern "C" void cbv_pipeline_destroy(cbv_pipeline* p)
         if (p->lane_stream[l]) (void)hipStreamDestroy(p->lane_stream[l]);
     }
     if (p->start_ev) (void)hipEventDestroy(p->start_ev);
+    if (p->scan_stream) {
+        (void)hipStreamSynchronize(p->scan_stream);
+        (void)hipStreamDestroy(p->scan_stream);
+    }
+    if (p->scan_done) (void)hipEventDestroy(p->scan_done);
+    if (p->main_done) (void)hipEventDestroy(p->main_done);
     if (p->copy_stream) {
         (void)hipStreamSynchronize(p->copy_stream);
         (void)hipStreamDestroy(p->copy_stream);
@@ -945,6 +968,7 @@ extern "C" int cbv_pipeline_configure(cbv_pipeline* p, const cbv_pipeline_config
     if (!p || !cfg) return CBV_ERR_ARG;
     cbv_ctx* ctx = p->ctx;
     CBV_HIP(ctx, hipSetDevice(ctx->device));
+    RC(join_scan(p)); // lanes and scan of the last run
     if (cfg->n_rois <= 0 || cfg->n_rois > CBV_MAX_SQUARES || cfg->board_size <= 0 || cfg->board_size > 4096)
         return cbv_fail(ctx, CBV_ERR_ARG, "cbv_pipeline_configure: bad board/roi configuration");
     if (cfg->history_size < 1 || cfg->history_size > 7) return cbv_fail(ctx, CBV_ERR_ARG, "history_size must be in 1..7");
@@ -1045,6 +1069,7 @@ extern "C" int cbv_pipeline_reset_state(cbv_pipeline* p)
     if (!p || !p->configured) return CBV_ERR_STATE;
     cbv_ctx* ctx = p->ctx;
     CBV_HIP(ctx, hipSetDevice(ctx->device));
+    RC(join_scan(p)); // lanes and scan of the last run
     CBV_HIP(ctx, hipMemsetAsync(p->d_state.p, 0, sizeof(ScanState) * p->cfg.n_rois, ctx->stream));
     CBV_HIP(ctx, hipMemsetAsync(p->d_noise_state.p, 0, sizeof(cbv_noise_state), ctx->stream));
     return CBV_OK;
@@ -1056,6 +1081,7 @@ extern "C" int cbv_pipeline_calibrate(cbv_pipeline* p, int slot)
     cbv_ctx* ctx = p->ctx;
     if (slot < 0 || slot >= p->max_frames) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_pipeline_calibrate: bad slot");
     CBV_HIP(ctx, hipSetDevice(ctx->device));
+    RC(join_scan(p)); // lanes and scan of the last run
     RC(launch_squares_calibrate(ctx, (const SquareDesc*)p->d_descs.p, p->cfg.n_rois, (const u8*)p->d_gray.p + p->plane_total * slot,
                                 (float*)p->d_mean.p, (float*)p->d_var.p, (float)p->cfg.initial_variance, nullptr));
     p->calibrated = true;
@@ -1067,6 +1093,7 @@ extern "C" int cbv_pipeline_upload(cbv_pipeline* p, int slot, const uint8_t* bgr
     if (!p || !bgr || slot < 0 || slot >= p->max_frames || stride < p->w * 3) return CBV_ERR_ARG;
     cbv_ctx* ctx = p->ctx;
     CBV_HIP(ctx, hipSetDevice(ctx->device));
+    RC(join_scan(p)); // lanes and scan of the last run
     CBV_HIP(ctx, hipMemcpy2DAsync(p->frames + p->g.frame_stride * slot, p->w * 3, bgr, stride, p->w * 3, p->h, hipMemcpyHostToDevice, ctx->stream));
     CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return CBV_OK;
@@ -1126,6 +1153,7 @@ extern "C" int cbv_pipeline_synth(cbv_pipeline* p, int slot0, int count, const u
     if (!p || !seeds || !Hinv9 || !boards || !scene || slot0 < 0 || count <= 0 || slot0 + count > p->max_frames) return CBV_ERR_ARG;
     cbv_ctx* ctx = p->ctx;
     CBV_HIP(ctx, hipSetDevice(ctx->device));
+    RC(join_scan(p)); // lanes and scan of the last run
     size_t o_seeds = 0, o_h = (size_t)count * 8, o_b = o_h + 72, o_s = (o_b + (size_t)count * 64 + 15) & ~(size_t)15;
     size_t total = o_s + sizeof(cbv_scene);
     CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1154,6 +1182,7 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
     // Lane 0 is the context's stream; lanes 1.. are worker streams forked from it and joined before
     // the temporal scan (which needs every frame's statistics, in order).
     hipStream_t main_stream = ctx->stream;
+    if (p->scan_pending && ranges_overlap(slot0, count, p->scan_s0, p->scan_cnt)) RC(join_scan(p)); // it still reads these slots' planes
     for (auto& c : p->copies) // ingest copies of these slots must have landed
         if (c.pending && ranges_overlap(slot0, count, c.s0, c.cnt)) {
             CBV_HIP(ctx, hipStreamWaitEvent(main_stream, c.ev, 0));
@@ -1211,10 +1240,29 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
     }
     ctx->stream = main_stream;
     if (rc_all) return rc_all;
+    if (!p->scan_stream) {
+        CBV_HIP(ctx, hipStreamCreateWithFlags(&p->scan_stream, hipStreamNonBlocking));
+        CBV_HIP(ctx, hipEventCreateWithFlags(&p->scan_done, hipEventDisableTiming));
+        CBV_HIP(ctx, hipEventCreateWithFlags(&p->main_done, hipEventDisableTiming));
+    }
+    CBV_HIP(ctx, hipEventRecord(p->main_done, main_stream));
+    CBV_HIP(ctx, hipStreamWaitEvent(p->scan_stream, p->main_done, 0));
     for (int l = 1; l < p->n_lanes; l++) {
         CBV_HIP(ctx, hipEventRecord(p->lane_done[l], p->lane_stream[l]));
-        CBV_HIP(ctx, hipStreamWaitEvent(main_stream, p->lane_done[l], 0));
+        CBV_HIP(ctx, hipStreamWaitEvent(p->scan_stream, p->lane_done[l], 0));
     }
+    if (p->host_ring) { // every lane has read its frames: a later cbv_pipeline_submit may overwrite these slots
+        if (!p->run_done) CBV_HIP(ctx, hipEventCreateWithFlags(&p->run_done, hipEventDisableTiming));
+        CBV_HIP(ctx, hipEventRecord(p->run_done, p->scan_stream));
+        p->last_run_s0 = slot0;
+        p->last_run_cnt = count;
+    }
+    ctx->stream = p->scan_stream;
+    struct Restore {
+        cbv_ctx* c;
+        hipStream_t s;
+        ~Restore() { c->stream = s; }
+    } restore{ctx, main_stream};
     ScanParams sp;
     sp.n = n;
     sp.history_size = cfg.history_size;
@@ -1233,12 +1281,10 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
     // NoiseHandler on the frames' visual_changes sets (game_session.py:165)
     RC(launch_noise(ctx, &((const cbv_frame_result*)p->d_results.p + slot0)->visual_changes, sizeof(cbv_frame_result) / 8, count,
                     (cbv_noise_state*)p->d_noise_state.p, (cbv_noise_result*)p->d_noise.p + slot0));
-    if (p->host_ring) { // lets a later cbv_pipeline_submit know when these slots may be overwritten
-        if (!p->run_done) CBV_HIP(ctx, hipEventCreateWithFlags(&p->run_done, hipEventDisableTiming));
-        CBV_HIP(ctx, hipEventRecord(p->run_done, main_stream));
-        p->last_run_s0 = slot0;
-        p->last_run_cnt = count;
-    }
+    CBV_HIP(ctx, hipEventRecord(p->scan_done, p->scan_stream));
+    p->scan_pending = true;
+    p->scan_s0 = slot0;
+    p->scan_cnt = count;
     return CBV_OK;
 }
 
@@ -1247,6 +1293,7 @@ extern "C" int cbv_pipeline_results(cbv_pipeline* p, int slot0, int count, cbv_f
     if (!p || !out || slot0 < 0 || count <= 0 || slot0 + count > p->max_frames) return CBV_ERR_ARG;
     cbv_ctx* ctx = p->ctx;
     CBV_HIP(ctx, hipSetDevice(ctx->device));
+    RC(join_scan(p)); // lanes and scan of the last run
     CBV_HIP(ctx, hipMemcpyAsync(out, (cbv_frame_result*)p->d_results.p + slot0, sizeof(cbv_frame_result) * count, hipMemcpyDeviceToHost, ctx->stream));
     CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return CBV_OK;
@@ -1257,6 +1304,7 @@ extern "C" int cbv_pipeline_noise_results(cbv_pipeline* p, int slot0, int count,
     if (!p || !out || !p->configured || slot0 < 0 || count <= 0 || slot0 + count > p->max_frames) return CBV_ERR_ARG;
     cbv_ctx* ctx = p->ctx;
     CBV_HIP(ctx, hipSetDevice(ctx->device));
+    RC(join_scan(p)); // lanes and scan of the last run
     CBV_HIP(ctx, hipMemcpyAsync(out, (cbv_noise_result*)p->d_noise.p + slot0, sizeof(cbv_noise_result) * count, hipMemcpyDeviceToHost, ctx->stream));
     CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return CBV_OK;
@@ -1283,6 +1331,7 @@ extern "C" int cbv_pipeline_download(cbv_pipeline* p, int which, int slot, uint8
     if (!p || !out || slot < 0 || slot >= p->max_frames) return CBV_ERR_ARG;
     cbv_ctx* ctx = p->ctx;
     CBV_HIP(ctx, hipSetDevice(ctx->device));
+    RC(join_scan(p)); // lanes and scan of the last run
     const u8* src;
     size_t bytes;
     if (which == 0) {
@@ -1309,6 +1358,7 @@ extern "C" int cbv_pipeline_hough(cbv_pipeline* p, int slot, cbv_hough_result* o
     cbv_ctx* ctx = p->ctx;
     if (!p->configured || !p->cfg.use_hough) return cbv_fail(ctx, CBV_ERR_STATE, "cbv_pipeline_hough: the HoughCircles stage is not configured");
     CBV_HIP(ctx, hipSetDevice(ctx->device));
+    RC(join_scan(p)); // lanes and scan of the last run
     CBV_HIP(ctx, hipMemcpyAsync(out, (const cbv_hough_result*)p->d_hough.p + (size_t)CBV_MAX_SQUARES * slot,
                                 sizeof(cbv_hough_result) * CBV_MAX_SQUARES, hipMemcpyDeviceToHost, ctx->stream));
     CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1320,6 +1370,7 @@ extern "C" int cbv_pipeline_square_stats(cbv_pipeline* p, int slot, cbv_sq_stats
     if (!p || !out || !p->configured || slot < 0 || slot >= p->max_frames) return CBV_ERR_ARG;
     cbv_ctx* ctx = p->ctx;
     CBV_HIP(ctx, hipSetDevice(ctx->device));
+    RC(join_scan(p)); // lanes and scan of the last run
     CBV_HIP(ctx, hipMemcpyAsync(out, (cbv_sq_stats*)p->d_stats.p + (size_t)p->cfg.n_rois * slot, sizeof(cbv_sq_stats) * p->cfg.n_rois,
                                 hipMemcpyDeviceToHost, ctx->stream));
     CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
