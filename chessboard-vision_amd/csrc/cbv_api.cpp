@@ -764,6 +764,9 @@ static int hough_cfg(cbv_ctx* ctx, const cbv_hough_params* prm, const std::vecto
 {
     if (!prm || !(prm->dp > 0) || prm->param1 < 0 || prm->param2 < 0 || !(prm->max_radius_ratio >= 0) || !(prm->min_radius_ratio >= 0))
         return cbv_fail(ctx, CBV_ERR_ARG, "HoughCircles parameters are invalid");
+    if (prm->max_radius_ratio > 4.0 || prm->min_radius_ratio > 4.0)
+        return cbv_fail(ctx, CBV_ERR_ARG, "HoughCircles radius ratios above 4 squares are not supported (got %g, %g)", prm->min_radius_ratio,
+                        prm->max_radius_ratio);
     memset(hc, 0, sizeof(*hc));
     hc->dp = (float)prm->dp < 1.f ? 1.f : (float)prm->dp;
     hc->canny_thr = (int)nearbyint(prm->param1);

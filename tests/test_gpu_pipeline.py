@@ -332,3 +332,34 @@ def test_ingest_ring_submit_run_overlap(gpu_ctx, oracle):
         a.submit(n - 1, 2)
     with pytest.raises(RuntimeError):
         ref.submit(0, 1)  # host ring never requested
+
+
+def test_error_paths_are_loud(gpu_ctx):
+    """Argument and state errors come back as CBV_ERR_* (RuntimeError in the wrappers) with a message; nothing is
+    silently clamped or routed to a fallback."""
+    from chessboard_vision_amd._squares import SquareSet
+    from chessboard_vision_amd.stream import BoardPipeline
+    p = BoardPipeline(W, H, 4)
+    with pytest.raises(RuntimeError):
+        p.run(0, 1)                                   # not configured
+    pts = S.scaled_corners(W, H)
+    with pytest.raises(RuntimeError, match="radius ratios"):
+        p.configure(pts, max_radius_ratio=5.0)
+    with pytest.raises(RuntimeError, match="history_size"):
+        p.configure(pts, history_size=9)
+    p.configure(pts)
+    for bad in ((-1, 1), (0, 0), (3, 2)):
+        with pytest.raises(RuntimeError, match="slot range"):
+            p.run(*bad)
+    with pytest.raises(RuntimeError):
+        p.calibrate_changes(9)
+    ss = SquareSet(gpu_ctx)
+    with pytest.raises(RuntimeError, match="no squares"):
+        ss.hough()
+    with pytest.raises(RuntimeError):
+        ss.load({0: np.zeros((300, 300), np.uint8)}, 5)   # beyond CBV_MAX_SQUARE_DIM
+    ss.load({0: np.zeros((40, 40), np.uint8)}, 5)
+    with pytest.raises(RuntimeError, match="radius ratios"):
+        ss.hough(max_radius_ratio=4.5)
+    with pytest.raises(RuntimeError, match="model requested"):
+        ss.stats(use_model=True)
