@@ -65,7 +65,7 @@ def _L():
             "cbv_board_is_check": (i32, [vp]), "cbv_board_push": (i32, [vp, u16]), "cbv_board_pop": (u16, [vp]),
             "cbv_board_ply": (i32, [vp]), "cbv_board_peek": (u16, [vp]), "cbv_board_perft": (u64, [vp, i32]),
             "cbv_game_process_occupancy": (i32, [vp, u64, C.POINTER(u16)]), "cbv_game_status_name": (C.c_char_p, [i32]),
-            "cbv_roi_bits_to_squares": (u64, [u64]),
+            "cbv_roi_bits_to_squares": (u64, [u64]), "cbv_game_infer_move": (i32, [vp, u64, C.POINTER(u16)]),
         }
         for name, (res, args) in proto.items():
             fn = getattr(lib, name)

@@ -706,6 +706,42 @@ int cbv_game_process_occupancy(cbv_board* b, uint64_t vision, cbv_move* move_out
     return CBV_GAME_NO_VALID_CHANGE;
 }
 
+int cbv_game_infer_move(const cbv_board* b, uint64_t vision, cbv_move* move_out)
+{
+    if (move_out) *move_out = CBV_MOVE_NONE;
+    if (!b) return 0;
+    const u64 logical = cbv_board_occupancy(b);
+    const u64 missing = logical & ~vision, extra = vision & ~logical;
+    std::vector<cbv_move> mv, cand;
+    gen_legal(b, mv);
+    auto in_legal = [&](cbv_move m) {
+        for (cbv_move x : mv)
+            if (x == m) return true;
+        return false;
+    };
+    auto add = [&](cbv_move m) {
+        for (cbv_move x : cand)
+            if (x == m) return;
+        cand.push_back(m);
+    };
+    // 1. origin vanished, destination appeared (queen promotion when the plain move is not legal)   game_session.py:235-248
+    for (u64 o = missing; o;) {
+        const int s = msb(o);
+        o &= ~bit(s);
+        for (u64 e = extra; e;) {
+            const int t = msb(e);
+            e &= ~bit(t);
+            if (in_legal(mk(s, t))) add(mk(s, t));
+            else if (in_legal(mk(s, t, QUEEN))) add(mk(s, t, QUEEN));
+        }
+    }
+    // 2. captures from a vanished origin onto a square vision still sees occupied   game_session.py:250-257
+    for (cbv_move m : mv)
+        if ((missing & bit(m_from(m))) && capture(b, m) && (vision & bit(m_to(m)))) add(m);
+    if (cand.size() == 1 && move_out) *move_out = cand[0];
+    return (int)cand.size();
+}
+
 uint64_t cbv_roi_bits_to_squares(uint64_t roi_bits)
 {
     u64 out = 0;

@@ -73,6 +73,12 @@ CBV_API int cbv_game_process_occupancy(cbv_board* b, uint64_t vision_occupancy, 
 /* the status strings the reference returns, indexed by the codes above */
 CBV_API const char* cbv_game_status_name(int status);
 
+/* GameSession._infer_move (game_session.py:229-265): the moves that explain the difference between the board and
+ * the vision occupancy — (vanished origin, appeared destination) pairs that are legal (queen promotion tried when
+ * the plain move is not), plus legal captures from a vanished origin onto a square vision sees occupied.  Returns
+ * the number of distinct candidates; *move_out is set only when it is exactly one.  The board is not changed. */
+CBV_API int cbv_game_infer_move(const cbv_board* b, uint64_t vision_occupancy, cbv_move* move_out);
+
 /* ROI-numbered bits of cbv_frame_result (bit 8 * row + col, row 0 = rank 8 of the warped board, or its 180-degree
  * turn when the pipeline was configured with rot180) -> python-chess square bits (grid_extractor.py:31-40 numbering: file = col, rank = 7 - row) */
 CBV_API uint64_t cbv_roi_bits_to_squares(uint64_t roi_bits);

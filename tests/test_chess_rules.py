@@ -197,3 +197,50 @@ def test_scripted_game_through_occupancy_words():
     assert played == ["e2e4", "e7e5", "g1f3", "b8c6", "f1b5", "a7a6", "b5a4", "g8f6", "e1g1", "f8e7", "f1e1", "b7b5",
                       "a4b3", "d7d6", "c2c3", "e8g8"]
     assert gs.get_fen() == "r1bq1rk1/2p1bppp/p1np1n2/1p2p3/4P3/1BP2N2/PP1P1PPP/RNBQR1K1 w - - 1 9"
+
+
+def test_infer_move_and_stable_tracker():
+    """GameSession._infer_move / _process_stable_move (game_session.py:181-265) on the native engine."""
+    from chessboard_vision_amd.game_state import StableMoveTracker, smart_scan_squares
+    gs = GameState()
+    now = [100.0]
+    events = []
+    tr = StableMoveTracker(gs, clock=lambda: now[0], after_move=lambda: events.append("synced"))
+    start = gs.get_board_occupancy()
+    assert tr.infer_move(start) == (None, 0)
+    e4 = _moved(gs, [(4, 1)], [(4, 3)])
+    assert tr.infer_move(e4)[0].uci() == "e2e4"
+    # 19 stable frames are not enough, the 20th pushes the move
+    for i in range(19):
+        assert tr.process(e4) is None
+    assert tr.process(e4).uci() == "e2e4" and events == ["synced"] and gs.get_turn_name() == "black"
+    # cooldown: the reply is seen at once but accepted only 2 s after the previous move
+    e5 = _moved(gs, [(4, 6)], [(4, 4)])
+    for i in range(25):
+        assert tr.process(e5) is None
+    now[0] += 2.5
+    assert tr.process(e5).uci() == "e7e5"
+    # a hand over the board (more than 4 differing squares) resets the count; NOISE_ACTIVE blocks acceptance
+    now[0] += 10
+    nf3 = _moved(gs, [(6, 0)], [(5, 2)])
+    for i in range(19):
+        tr.process(nf3)
+    hand = set(nf3) - {(0, 1), (1, 1), (2, 1)} | {(3, 3), (3, 4)}
+    assert tr.process(hand) is None and tr.stable_count == 0
+    for i in range(19):
+        assert tr.process(nf3) is None
+    assert tr.process(nf3, noise_active=True) is None
+    assert tr.process(nf3).uci() == "g1f3"
+    # ambiguity: after 1.e4 d5 a vanished e4 pawn with d5 still occupied is exd5 only; a vanished piece that could
+    # capture two ways yields two candidates and no move
+    amb = GameState()
+    amb.set_fen("4k3/8/8/2p1p3/3P4/8/8/4K3 w - - 0 1")
+    t2 = StableMoveTracker(amb, clock=lambda: 1e9)
+    assert t2.infer_move(_moved(amb, [(3, 3)], [])) == (None, 2)
+    # promotion is inferred as a queen
+    pr = GameState()
+    pr.set_fen("4k3/P7/8/8/8/8/8/4K3 w - - 0 1")
+    assert StableMoveTracker(pr).infer_move(_moved(pr, [(0, 6)], [(0, 7)]))[0].uci() == "a7a8q"
+    # smart scan set of the start position: 32 occupied squares + the (file, 7 - rank) images of ranks 3 and 4
+    sq = smart_scan_squares(GameState())
+    assert len(sq) == 32 + 16 and (0, 5) in sq and (0, 4) in sq and (0, 2) not in sq
