@@ -363,3 +363,32 @@ def test_error_paths_are_loud(gpu_ctx):
         ss.hough(max_radius_ratio=4.5)
     with pytest.raises(RuntimeError, match="model requested"):
         ss.stats(use_model=True)
+
+
+def test_stream_to_moves_end_to_end(gpu_ctx):
+    """Whole loop on the synthetic stream: pipeline -> per-frame stable occupancy + NoiseHandler state (device) ->
+    StableMoveTracker (20 stable frames, cooldown) -> GameState; the first six plies of the script come out."""
+    from chessboard_vision_amd.game_state import GameState, StableMoveTracker
+    from chessboard_vision_amd.stream import BoardPipeline
+    fpp, plies = 26, 6
+    n = fpp * plies + 24
+    p = BoardPipeline(W, H, n)
+    p.configure(S.scaled_corners(W, H), profile={}, chunk=25)
+    p.synth(0, n, scene="normal", frames_per_ply=fpp)
+    p.run(0, n)
+    res, noise = p.results(0, n), p.noise_results(0, n)
+    gs = GameState()
+    t = [0.0]
+    tracker = StableMoveTracker(gs, clock=lambda: t[0])
+    moves = []
+    for i in range(n):
+        t[0] += 1.0 / 8.0   # an 8 fps camera: 26 frames a ply outlast the 2 s cooldown
+        state, _ = noise[i]
+        m = tracker.process(p.occupied(res[i]), noise_active=(state.name == "NOISE_ACTIVE"))
+        if m is not None:
+            moves.append((i, m.uci()))
+    assert [u for _, u in moves] == ["e2e4", "e7e5", "g1f3", "b8c6", "f1b5", "a7a6"]
+    # a move is accepted 20+ frames after its ply starts (stability) and before the next ply starts
+    for k, (i, _) in enumerate(moves):
+        assert (k + 1) * fpp + 19 <= i < (k + 2) * fpp + 24, (k, i)
+    assert gs.get_fen().startswith("r1bqkbnr/1ppp1ppp/p1n5/1B2p3/4P3/5N2/PPPP1PPP/RNBQK2R w KQkq -")
