@@ -167,6 +167,9 @@ def load():
         "cbv_squares_ema": (i32, [vp, dbl, vp]),
         "cbv_squares_set_ref": (i32, [vp, vp]),
         "cbv_squares_stats": (i32, [vp, i32, i32, dbl, P(SqStats)]),
+        "cbv_board_corners_from_edges": (i32, [u8p, i32, i32, i32, C.POINTER(C.c_int32), C.POINTER(i32)]),
+        "cbv_largest_contour_polygon": (i32, [u8p, i32, i32, i32, dbl, C.POINTER(C.c_int32), i32, C.POINTER(dbl), C.POINTER(i32)]),
+        "cbv_find_chessboard_corners": (i32, [vp, u8p, i32, i32, i32, C.POINTER(C.c_int32), u8p, i32]),
         "cbv_canny": (i32, [vp, u8p, i32, i32, i32, i32, dbl, dbl, u8p, i32]),
         "cbv_squares_hough": (i32, [vp, P(HoughParams), P(HoughResult)]),
         "cbv_squares_get": (i32, [vp, i32, i32, vp]),

@@ -55,3 +55,35 @@ def warp_image(img, points, display_size=(1280, 720), margin=100):
     matrix = get_perspective_transform(pts1, pts2)
     warped = warp_perspective(img, matrix, (board_size, board_size))
     return warped, matrix, board_size
+
+
+def corners_from_edges(edges):
+    """Host half of find_chessboard_corners: (approx polygon int32 (4,1,2) or None, number of external contours)."""
+    from . import _native as N
+    import ctypes as C
+    e = np.ascontiguousarray(np.asarray(edges, dtype=np.uint8))
+    pts = (C.c_int32 * 8)()
+    n = C.c_int(0)
+    rc = N.load().cbv_board_corners_from_edges(e.ctypes.data, e.shape[1], e.shape[0], e.strides[0], pts, C.byref(n))
+    if rc < 0:
+        raise ValueError("corners_from_edges: bad arguments")
+    return (np.array(pts, np.int32).reshape(4, 1, 2) if rc == 1 else None), n.value
+
+
+def find_chessboard_corners(img, debug=False):
+    """board_detection.py:4-28: the four corners (reordered TL, TR, BL, BR; int32 (4,1,2)) of the largest
+    four-cornered contour of the dilated Canny edges, or an empty array.  Pixel stages on the GPU, contour
+    following on the host (cbv_find_chessboard_corners); `debug=True` also returns the dilated edge image
+    instead of showing a window."""
+    from . import _native as N
+    import ctypes as C
+    a = N.as_bgr(img)
+    ctx = N.context()
+    pts = (C.c_int32 * 8)()
+    dil = np.empty(a.shape[:2], np.uint8) if debug else None
+    rc = ctx.lib.cbv_find_chessboard_corners(ctx.h, N.ptr(a), a.shape[1], a.shape[0], a.strides[0], pts,
+                                             dil.ctypes.data if debug else None, dil.strides[0] if debug else 0)
+    if rc < 0:
+        ctx.check(rc)
+    out = reorder(np.array(pts, np.int32).reshape(4, 1, 2)) if rc == 1 else np.array([])
+    return (out, dil) if debug else out

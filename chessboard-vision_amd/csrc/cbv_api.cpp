@@ -460,6 +460,51 @@ extern "C" int cbv_canny(cbv_ctx* ctx, const uint8_t* img, int w, int h, int str
     return CBV_OK;
 }
 
+extern "C" int cbv_board_corners_from_edges(const uint8_t* edges, int w, int h, int stride, int32_t* pts8, int* n_contours)
+{
+    if (!edges || !pts8 || w <= 0 || h <= 0 || stride < w) return CBV_ERR_ARG;
+    std::vector<u8> tight((size_t)w * h);
+    for (int y = 0; y < h; y++) memcpy(tight.data() + (size_t)y * w, edges + (size_t)y * stride, (size_t)w);
+    return board_corners_from_edges(tight.data(), w, h, pts8, n_contours);
+}
+
+extern "C" int cbv_largest_contour_polygon(const uint8_t* edges, int w, int h, int stride, double eps_frac, int32_t* pts, int cap,
+                                           double* area, int* contour_len)
+{
+    if (!edges || !pts || w <= 0 || h <= 0 || stride < w || cap <= 0) return CBV_ERR_ARG;
+    std::vector<u8> tight((size_t)w * h);
+    for (int y = 0; y < h; y++) memcpy(tight.data() + (size_t)y * w, edges + (size_t)y * stride, (size_t)w);
+    return largest_contour_polygon(tight.data(), w, h, eps_frac, pts, cap, area, contour_len);
+}
+
+extern "C" int cbv_find_chessboard_corners(cbv_ctx* ctx, const uint8_t* bgr, int w, int h, int stride, int32_t* pts8,
+                                           uint8_t* dilated_out, int dilated_stride)
+{
+    RC(check_img(ctx, bgr, w, h, stride, 3, "cbv_find_chessboard_corners"));
+    if (!pts8) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_find_chessboard_corners: null output");
+    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    RC(upload(ctx, &ctx->in, bgr, w * 3, h, stride));
+    const size_t plane = ((size_t)w * h + 255) & ~(size_t)255;
+    RC(dev_ensure(ctx, &ctx->a, plane * 3 + 256));
+    u8* blur = (u8*)ctx->a.p;
+    u8* edges = blur + plane;
+    u8* dil = edges + plane;
+    int coef[16] = {0};
+    build_gaussian_q8_sigma(7, 1.0, coef);                      // cv2.GaussianBlur(gray, (7, 7), 1)
+    int* coef_dev = (int*)(dil + plane);
+    CBV_HIP(ctx, hipMemcpyAsync(coef_dev, coef, sizeof(int) * 16, hipMemcpyHostToDevice, ctx->stream));
+    RC(launch_gray_gauss(ctx, (const u8*)ctx->in.p, w, h, w * 3, 3, coef_dev, 7, blur));
+    RC(launch_canny(ctx, blur, w, h, w, 1, 30, 100, edges, &ctx->b)); // cv2.Canny(blur, 30, 100)
+    RC(launch_dilate_rect(ctx, edges, w, h, 6, dil));           // three 5x5 dilations = one 13x13
+    std::vector<u8> host((size_t)w * h);
+    CBV_HIP(ctx, hipMemcpyAsync(host.data(), dil, (size_t)w * h, hipMemcpyDeviceToHost, ctx->stream));
+    CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (dilated_out)
+        for (int y = 0; y < h; y++) memcpy(dilated_out + (size_t)y * dilated_stride, host.data() + (size_t)y * w, (size_t)w);
+    int n_contours = 0;
+    return board_corners_from_edges(host.data(), w, h, pts8, &n_contours);
+}
+
 // enhancement chain on device buffers: src -> (A, B ping-pong) ; result pointer returned.
 // When `fold_norm` the final normalize pass is skipped and the caller applies S.norm_lut downstream.
 static int enhance_dev(cbv_ctx* ctx, const u8* src, u8* A, u8* B, Geom g, const cbv_enhance_params* P, SmallLayout S,

@@ -173,6 +173,11 @@ int launch_threshold(cbv_ctx* ctx, const u8* blur, u8* binary, const u32* aux, i
 int launch_synth(cbv_ctx* ctx, u8* dst, Geom g, const u64* seeds_dev, const double* hinv_dev, const u8* boards_dev,
                  const cbv_scene* scene_dev, int batch);
 
+void build_gaussian_q8_sigma(int k, double sigma, int* coef);
+int launch_gray_gauss(cbv_ctx* ctx, const u8* src, int w, int h, int stride, int cn, const int* coef_dev, int k, u8* dst);
+int launch_dilate_rect(cbv_ctx* ctx, const u8* src, int w, int h, int r, u8* dst);
+int largest_contour_polygon(const uint8_t* img, int w, int h, double eps_frac, int32_t* pts, int cap, double* area_out, int* contour_len);
+int board_corners_from_edges(const uint8_t* dilated, int w, int h, int32_t pts[8], int* n_contours);
 int launch_canny(cbv_ctx* ctx, const u8* src, int w, int h, int stride, int cn, int low, int high, u8* edges, DevBuf* scratch);
 
 // squares

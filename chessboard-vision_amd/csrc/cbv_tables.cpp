@@ -154,6 +154,36 @@ int build_bilateral_tabs(int d, double sigma_color, double sigma_space, Bilatera
     return 0;
 }
 
+// cv2.GaussianBlur((k,k), sigma) 8-bit kernel in 8.8 fixed point for an explicit sigma > 0: exp kernel, normalised,
+// rounded with error diffusion so that the taps sum to 256 (OpenCV's fixed-point Gaussian kernel)
+void build_gaussian_q8_sigma(int k, double sigma, int* coef)
+{
+    if (!(sigma > 0)) {
+        build_gaussian_q8(k, coef);
+        return;
+    }
+    const double scale2 = -0.5 / (sigma * sigma);
+    std::vector<double> cf(k);
+    double sum = 0;
+    for (int i = 0; i < k; i++) {
+        const double x = i - (k - 1) * 0.5;
+        cf[i] = exp(scale2 * x * x);
+        sum += cf[i];
+    }
+    sum = 1. / sum;
+    const int n2 = k / 2;
+    double err = 0;
+    long long s = 0;
+    for (int i = 0; i < n2; i++) {
+        const double adj = cf[i] * sum * 256.0 + err;
+        const long long v0 = (long long)floor(adj + 0.5);
+        err = adj - (double)v0;
+        coef[i] = coef[k - 1 - i] = (int)v0;
+        s += v0;
+    }
+    coef[n2] = (int)(256 - 2 * s);
+}
+
 // cv2.GaussianBlur((k,k),0) 8-bit kernel in 8.8 fixed point
 void build_gaussian_q8(int k, int* coef)
 {

@@ -127,3 +127,88 @@ int launch_canny(cbv_ctx* ctx, const u8* src, int w, int h, int stride, int cn, 
     CBV_HIP(ctx, hipGetLastError());
     return CBV_OK;
 }
+
+// ---------------------------------------------------------------------------
+// find_chessboard_corners' pixel stages (board_detection.py:9-14): BGR2GRAY + GaussianBlur((k, k), sigma) in
+// OpenCV's 8.8 fixed point (REFLECT_101), and cv2.dilate with a (2r+1)^2 rectangle (pixels outside the image do
+// not take part; three 5x5 dilations = one 13x13).  32 x 32 output tiles, separable through LDS.
+// ---------------------------------------------------------------------------
+#define GB_T 32
+#define GB_RMAX 7
+
+__global__ __launch_bounds__(256) void k_gray_gauss(const u8* __restrict__ src, int w, int h, int stride, int cn,
+                                                     const int* __restrict__ coef, int k, u8* __restrict__ dst)
+{
+    __shared__ u8 g[(GB_T + 2 * GB_RMAX) * (GB_T + 2 * GB_RMAX)];
+    __shared__ u16 hb[(GB_T + 2 * GB_RMAX) * GB_T];
+    __shared__ int cf[2 * GB_RMAX + 1];
+    const int r = k >> 1, L = GB_T + 2 * r;
+    const int x0 = blockIdx.x * GB_T, y0 = blockIdx.y * GB_T;
+    if (threadIdx.x < k) cf[threadIdx.x] = coef[threadIdx.x];
+    for (int i = threadIdx.x; i < L * L; i += 256) {
+        const int ly = i / L, lx = i - ly * L;
+        const int sy = d_reflect101(y0 - r + ly, h), sx = d_reflect101(x0 - r + lx, w);
+        const u8* p = src + (size_t)sy * stride + (size_t)sx * cn;
+        g[ly * L + lx] = (u8)(cn == 3 ? d_gray(p[0], p[1], p[2]) : p[0]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < L * GB_T; i += 256) {
+        const int ly = i / GB_T, lx = i - ly * GB_T;
+        int acc = 0;
+        for (int t = 0; t < k; t++) acc += cf[t] * g[ly * L + lx + t];
+        hb[ly * GB_T + lx] = (u16)acc;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < GB_T * GB_T; i += 256) {
+        const int ly = i / GB_T, lx = i - ly * GB_T;
+        if (x0 + lx >= w || y0 + ly >= h) continue;
+        u32 acc = 0;
+        for (int t = 0; t < k; t++) acc += (u32)cf[t] * hb[(ly + t) * GB_T + lx];
+        dst[(size_t)(y0 + ly) * w + x0 + lx] = (u8)((acc + (1u << 15)) >> 16);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dilate_rect(const u8* __restrict__ src, int w, int h, int r, u8* __restrict__ dst)
+{
+    __shared__ u8 g[(GB_T + 2 * GB_RMAX) * (GB_T + 2 * GB_RMAX)];
+    __shared__ u8 hb[(GB_T + 2 * GB_RMAX) * GB_T];
+    const int L = GB_T + 2 * r;
+    const int x0 = blockIdx.x * GB_T, y0 = blockIdx.y * GB_T;
+    for (int i = threadIdx.x; i < L * L; i += 256) {
+        const int ly = i / L, lx = i - ly * L;
+        const int sy = y0 - r + ly, sx = x0 - r + lx;
+        g[ly * L + lx] = (sx >= 0 && sx < w && sy >= 0 && sy < h) ? src[(size_t)sy * w + sx] : 0; // outside never wins a max
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < L * GB_T; i += 256) {
+        const int ly = i / GB_T, lx = i - ly * GB_T;
+        int m = 0;
+        for (int t = 0; t <= 2 * r; t++) m = max(m, (int)g[ly * L + lx + t]);
+        hb[ly * GB_T + lx] = (u8)m;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < GB_T * GB_T; i += 256) {
+        const int ly = i / GB_T, lx = i - ly * GB_T;
+        if (x0 + lx >= w || y0 + ly >= h) continue;
+        int m = 0;
+        for (int t = 0; t <= 2 * r; t++) m = max(m, (int)hb[(ly + t) * GB_T + lx]);
+        dst[(size_t)(y0 + ly) * w + x0 + lx] = (u8)m;
+    }
+}
+
+int launch_gray_gauss(cbv_ctx* ctx, const u8* src, int w, int h, int stride, int cn, const int* coef_dev, int k, u8* dst)
+{
+    if (k < 1 || k > 2 * GB_RMAX + 1 || !(k & 1)) return cbv_fail(ctx, CBV_ERR_UNSUPPORTED, "Gaussian kernel size %d is not supported (odd, <= 15)", k);
+    hipLaunchKernelGGL(k_gray_gauss, dim3((w + GB_T - 1) / GB_T, (h + GB_T - 1) / GB_T), dim3(256), 0, ctx->stream, src, w, h, stride, cn,
+                       coef_dev, k, dst);
+    CBV_HIP(ctx, hipGetLastError());
+    return CBV_OK;
+}
+
+int launch_dilate_rect(cbv_ctx* ctx, const u8* src, int w, int h, int r, u8* dst)
+{
+    if (r < 0 || r > GB_RMAX) return cbv_fail(ctx, CBV_ERR_UNSUPPORTED, "dilation radius %d is not supported (<= 7)", r);
+    hipLaunchKernelGGL(k_dilate_rect, dim3((w + GB_T - 1) / GB_T, (h + GB_T - 1) / GB_T), dim3(256), 0, ctx->stream, src, w, h, r, dst);
+    CBV_HIP(ctx, hipGetLastError());
+    return CBV_OK;
+}

@@ -226,6 +226,21 @@ CBV_API int cbv_squares_geometry(cbv_squares* sq, int index, int* w, int* h);
 CBV_API int cbv_canny(cbv_ctx* ctx, const uint8_t* img, int w, int h, int stride, int cn, double threshold1,
                       double threshold2, uint8_t* edges, int edges_stride);
 
+/* board_detection.find_chessboard_corners (board_detection.py:4-46) up to, not including, reorder(): BGR2GRAY,
+ * GaussianBlur((7,7), 1), Canny(30, 100), dilate(5x5, 3 iterations) on the GPU; findContours(RETR_EXTERNAL,
+ * CHAIN_APPROX_NONE), contourArea > 100000, approxPolyDP(0.02 * arcLength) with four vertices, largest area on the
+ * host.  Returns 1 and the polygon's four (x, y) vertices in pts8, 0 when no contour qualifies, negative on error.
+ * dilated_out (optional) receives the dilated edge image.  Calibration-time code; parity unpinned. */
+/* The host half of it alone (no GPU): external contours of a 0 / non-zero image -> the largest contour with
+ * area > 100000 whose approxPolyDP(0.02 * arcLength) has four vertices.  n_contours (optional) = contours found. */
+CBV_API int cbv_board_corners_from_edges(const uint8_t* edges, int w, int h, int stride, int32_t* pts8, int* n_contours);
+/* Inspection helper: approxPolyDP (eps = eps_frac * arcLength) of the largest external contour; returns its vertex
+ * count (the first `cap` are written), its area and its length in pixels. */
+CBV_API int cbv_largest_contour_polygon(const uint8_t* edges, int w, int h, int stride, double eps_frac, int32_t* pts,
+                                        int cap, double* area, int* contour_len);
+CBV_API int cbv_find_chessboard_corners(cbv_ctx* ctx, const uint8_t* bgr, int w, int h, int stride, int32_t* pts8,
+                                        uint8_t* dilated_out, int dilated_stride);
+
 /* ------------------------------------------------------------------ */
 /* device-resident batched pipeline: enhance -> warp -> 64-square detect */
 /* over frames that stay in HBM (bench configs C2..C5)                  */

@@ -158,3 +158,48 @@ def test_noise_handler_goldens():
     assert seen == set(MESSAGES)  # every transition of the machine is covered by the goldens
     h.reset()
     assert h.state == NoiseState.IDLE and h.stable_count == 0 and len(h.pending_squares) == 0
+
+
+def _quad_mask(w, h, pts):
+    yy, xx = np.mgrid[0:h, 0:w]
+    m = np.ones((h, w), bool)
+    P = np.array(pts, float)
+    for i in range(4):
+        a, b = P[i], P[(i + 1) % 4]
+        m &= ((b[0] - a[0]) * (yy - a[1]) - (b[1] - a[1]) * (xx - a[0])) >= 0
+    return m
+
+
+def test_corners_from_edges_known_answers():
+    """Host half of find_chessboard_corners (findContours EXTERNAL + contourArea + approxPolyDP, restated): a filled
+    convex quadrilateral comes back as exactly its four vertices, counter-clockwise from the top-left one; nested
+    components are not external contours; small or non-quadrilateral shapes do not qualify.  No cv2 to pin against."""
+    from chessboard_vision_amd.board_detection import corners_from_edges, reorder
+    w, h = 1280, 720
+    pts = [(300, 100), (900, 140), (950, 650), (260, 600)]
+    m = _quad_mask(w, h, pts).astype(np.uint8) * 255
+    poly, n = corners_from_edges(m)
+    assert n == 1 and poly.reshape(4, 2).tolist() == [[300, 100], [260, 600], [950, 650], [900, 140]]
+    assert reorder(poly).reshape(4, 2).tolist() == [[300, 100], [900, 140], [260, 600], [950, 650]]
+    ring = m.copy()
+    ring[_quad_mask(w, h, [(320, 120), (880, 158), (930, 630), (280, 582)])] = 0
+    ring[10:30, 10:60] = 255        # a small blob outside: a second external contour, too small to qualify
+    ring[400:402, 600:640] = 255    # a blob inside the ring's hole: not an external contour
+    poly2, n2 = corners_from_edges(ring)
+    assert n2 == 2 and poly2.reshape(4, 2).tolist() == poly.reshape(4, 2).tolist()
+    assert corners_from_edges(np.zeros((50, 60), np.uint8)) == (None, 0)
+    small = np.zeros((300, 300), np.uint8)
+    small[50:250, 50:250] = 255      # area 39601 < 100000
+    assert corners_from_edges(small) == (None, 1)
+    yy, xx = np.mgrid[0:700, 0:700]
+    disc = (((xx - 350) ** 2 + (yy - 350) ** 2) <= 300 ** 2).astype(np.uint8) * 255   # large, but not four-cornered
+    assert corners_from_edges(disc)[0] is None
+    single = np.zeros((20, 20), np.uint8)
+    single[5, 5] = 255
+    single[10:12, 10:14] = 255
+    assert corners_from_edges(single) == (None, 2)
+    # an axis-aligned rectangle touching the image border
+    edge = np.zeros((400, 500), np.uint8)
+    edge[0:400, 0:300] = 255
+    p3, _ = corners_from_edges(edge)
+    assert sorted(p3.reshape(4, 2).tolist()) == [[0, 0], [0, 399], [299, 0], [299, 399]]

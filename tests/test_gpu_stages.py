@@ -412,3 +412,46 @@ def test_refine_grid_matches_oracle_restatement(gpu_ctx, oracle):
     assert gx == ref_lines(np.sum(edges, axis=0), 620) and gy == ref_lines(np.sum(edges, axis=1), 620)
     assert all(abs(v - 77.5 * i) <= 3 for i, v in enumerate(gx)) and all(abs(v - 77.5 * i) <= 3 for i, v in enumerate(gy))
     assert len(SmartGridExtractor().split_board(warped)) == 64
+
+
+def _framed(frame, corners, grow=0.035, colour=(205, 210, 215)):
+    """The synthetic camera frame with a light wooden rim painted around the playing area (real boards have one; the
+    generator's dark squares otherwise melt into the dark table and the board's outline has gaps)."""
+    h, w = frame.shape[:2]
+    c = np.float32(corners).reshape(4, 2)
+    tl, tr, bl, br = c
+    ring = np.float32([tl, tr, br, bl])
+    centre = ring.mean(axis=0)
+    outer = centre + (ring - centre) * (1 + grow)
+    yy, xx = np.mgrid[0:h, 0:w]
+
+    def inside(poly):
+        m = np.ones((h, w), bool)
+        for i in range(4):
+            a, b = poly[i], poly[(i + 1) % 4]
+            m &= ((b[0] - a[0]) * (yy - a[1]) - (b[1] - a[1]) * (xx - a[0])) >= 0
+        return m
+    out = frame.copy()
+    out[inside(outer) & ~inside(ring)] = colour
+    # order back to TL, TR, BL, BR
+    return out, np.float32([outer[0], outer[1], outer[3], outer[2]])
+
+
+def test_find_chessboard_corners_on_synthetic_frames(gpu_ctx, oracle):
+    """board_detection.find_chessboard_corners (board_detection.py:4-28): on synthetic camera frames with a board rim
+    the rim's quadrilateral comes back, ordered TL, TR, BL, BR.  approxPolyDP runs with eps = 2 % of the perimeter
+    (60-120 px here), so a vertex is a contour point near the corner, not the corner itself: within 20 px of the
+    dilated rim's corner; a frame without a large quadrilateral gives an empty array.  Pixel stages on the GPU,
+    contours on the host; parity unpinned (no cv2)."""
+    from chessboard_vision_amd.board_detection import find_chessboard_corners, warp_image
+    for (w, h) in ((1920, 1080), (1280, 720)):
+        f, true = _framed(oracle_frame(w, h, "normal", frame_idx=0), S.scaled_corners(w, h))
+        got, dil = find_chessboard_corners(f, debug=True)
+        assert got.shape == (4, 1, 2) and got.dtype == np.int32 and dil.shape == (h, w), (w, h)
+        err = np.abs(got.reshape(4, 2).astype(np.float32) - true).max()
+        assert err <= 20, (w, h, got.reshape(4, 2).tolist(), true.tolist())
+        warped, _, size = warp_image(f, got)
+        assert warped.shape == (620, 620, 3) and size == 620
+    assert find_chessboard_corners(np.full((480, 640, 3), 90, np.uint8)).size == 0
+    small = _framed(oracle_frame(480, 360, "normal", frame_idx=0), S.scaled_corners(480, 360))[0]
+    assert find_chessboard_corners(small).size == 0          # the board covers < 100000 px here
