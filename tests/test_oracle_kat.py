@@ -246,3 +246,19 @@ def test_detect_piece_hough_branch(oracle):
     assert r_small["has_piece"] and r_small["method"] == "tower_top" and r_small["confidence"] == 0.75
     flat = np.full((77, 77, 3), 100, np.uint8)
     assert detect_piece(flat, hough={})[0]["has_piece"] is False
+
+
+@pytest.mark.parametrize("rad", [23, 25, 28, 30, 32, 35, 37])
+def test_hough_band_of_the_reference_piece_stats(oracle, rad):
+    """piece_stats.txt of the reference (its detector on a real board, 77-px squares) lists every piece as method
+    'hough', confidence 90 %, radius 23..37 px.  Not a pin (those are real images), but a plausibility band: the
+    restated chain gives the same method and confidence and recovers the radius of drawn pieces across that band,
+    with the shipped detector settings (min_radius 25 %, max_radius 55 %)."""
+    from ref_logic import detect_piece
+    yy, xx = np.mgrid[0:77, 0:77]
+    rng = np.random.default_rng(rad)
+    img = np.where((xx - 38) ** 2 + (yy - 38) ** 2 <= rad * rad, 215, 70).astype(np.int16) + rng.integers(-5, 6, (77, 77))
+    sq = np.dstack([np.clip(img, 0, 255).astype(np.uint8)] * 3)
+    res = detect_piece(sq, hough=dict(min_radius_ratio=0.25, max_radius_ratio=0.55))[0]
+    assert res["has_piece"] and res["method"] == "hough" and res["confidence"] == 0.9
+    assert abs(res["radius"] - rad) <= 2 and abs(res["center"][0] - 38) <= 2 and abs(res["center"][1] - 38) <= 2
