@@ -455,3 +455,26 @@ def test_find_chessboard_corners_on_synthetic_frames(gpu_ctx, oracle):
     assert find_chessboard_corners(np.full((480, 640, 3), 90, np.uint8)).size == 0
     small = _framed(oracle_frame(480, 360, "normal", frame_idx=0), S.scaled_corners(480, 360))[0]
     assert find_chessboard_corners(small).size == 0          # the board covers < 100000 px here
+
+
+@pytest.mark.parametrize("d,sc,ss", [(3, 40.0, 10.0), (5, 75.0, 75.0), (7, 20.0, 3.0), (9, 150.0, 1.5), (-1, 30.0, 1.0)])
+@pytest.mark.parametrize("shape", [(97, 131), (64, 128), (33, 35)])
+def test_bilateral_other_diameters_and_odd_shapes(gpu_ctx, oracle, d, sc, ss, shape):
+    """cbv_reduce_noise beyond the reference's fixed (9, 75, 75): every radius template, sigma-derived diameter
+    (d <= 0), widths that are no multiple of 4 and strided inputs (the unaligned byte path)."""
+    rng = np.random.default_rng(abs(d) * 100 + shape[0])
+    h, w = shape
+    big = rng.integers(0, 256, (h, w + 5, 3), dtype=np.uint8)
+    big[h // 3:2 * h // 3, w // 4:w // 2] //= 3          # a dark patch: large colour distances at its edge
+    f = big[:, 2:2 + w]                                  # a view: row stride 3 * (w + 5), odd alignment
+    out = np.empty((h, w, 3), np.uint8)
+    gpu_ctx.check(gpu_ctx.lib.cbv_reduce_noise(gpu_ctx.h, f.ctypes.data, w, h, f.strides[0], d, sc, ss, out.ctypes.data, out.strides[0]))
+    want = oracle.bilateral(np.ascontiguousarray(f), d, sc, ss)
+    assert np.array_equal(out, want), (d, sc, ss, shape, int((out != want).sum()))
+
+
+def test_bilateral_rejects_diameters_beyond_the_tile_halo(gpu_ctx):
+    f = np.zeros((32, 32, 3), np.uint8)
+    out = np.empty_like(f)
+    with pytest.raises(RuntimeError, match="radius"):
+        gpu_ctx.check(gpu_ctx.lib.cbv_reduce_noise(gpu_ctx.h, f.ctypes.data, 32, 32, 96, 15, 10.0, 10.0, out.ctypes.data, 96))
