@@ -565,12 +565,26 @@ __global__ __launch_bounds__(256) void k_sharpen(const u8* __restrict__ src, u8*
 #define SHB_TH 16                   // tile height in rows
 #define SHB_PITCH (SHB_TB + 32)     // LDS row: 16 B halo | 1024 B | 16 B halo
 
+#ifdef SH_TIMING
+// diagnostic build: per-workgroup phase stamps of k_sharpen_box (tools/sharpen_timeline.py)
+#define SH_MAX_STAMPS (1 << 16)
+__device__ unsigned long long g_sh_stamps[SH_MAX_STAMPS * 5];
+__device__ unsigned int g_sh_count;
+#define SH_STAMP(k) do { if (threadIdx.x == 0) sh_t[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SH_STAMP(k) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(256) void k_sharpen_box(const u8* __restrict__ src, u8* __restrict__ dst,
                                                       u32* __restrict__ aux, int tiles_total, Geom g, float a, float ca,
                                                       int tiles_xn, int tiles_n)
 {
     __shared__ __attribute__((aligned(16))) u8 tile[(SHB_TH + 2) * SHB_PITCH];
     __shared__ int red[8];
+#ifdef SH_TIMING
+    unsigned long long sh_t[4] = {0, 0, 0, 0};
+#endif
+    SH_STAMP(0);
     const int tid = xcd_remap(blockIdx.x, tiles_n);
     const int tyi = tid / tiles_xn, txi = tid - tyi * tiles_xn;
     const int xb0 = txi * SHB_TB, y0 = tyi * SHB_TH;
@@ -579,30 +593,50 @@ __global__ __launch_bounds__(256) void k_sharpen_box(const u8* __restrict__ src,
     u8* df = dst + fo;
     const int wb = g.w * 3;
     const bool al16 = (g.stride & 15) == 0;
-    // stage rows y0-1 .. y0+16, bytes [xb0-16, xb0+1040) as 66 uint4 per row
-    for (int i = threadIdx.x; i < (SHB_TH + 2) * (SHB_PITCH / 16); i += blockDim.x) {
-        const int r = i / (SHB_PITCH / 16), c = i - r * (SHB_PITCH / 16);
-        const int sy = d_reflect101(y0 - 1 + r, g.h);
-        const int bs = xb0 - 16 + c * 16;
-        uint4 v;
-        if (al16 && bs >= 0 && bs + 16 <= wb) {
-            v = *(const uint4*)(sf + (size_t)sy * g.stride + bs);
-        } else {
+    // stage rows y0-1 .. y0+16, bytes [xb0-16, xb0+1040) as 66 uint4 per row.  All of a lane's loads are issued
+    // before the first one is consumed: written as one loop (load, store to LDS, next) the compiler serialises
+    // five global-memory latencies per workgroup (measured with SH_TIMING: 21 k of a workgroup's 30 k clocks).
+    constexpr int SHB_VPR = SHB_PITCH / 16, SHB_NV = (SHB_TH + 2) * SHB_VPR, SHB_VPT = (SHB_NV + 255) / 256;
+    uint4 stg[SHB_VPT];
+    bool plain[SHB_VPT];
+#pragma unroll
+    for (int k = 0; k < SHB_VPT; k++) {
+        const int i = threadIdx.x + k * 256;
+        plain[k] = false;
+        if (i < SHB_NV) {
+            const int r = i / SHB_VPR, c = i - r * SHB_VPR;
+            const int sy = d_reflect101(y0 - 1 + r, g.h);
+            const int bs = xb0 - 16 + c * 16;
+            plain[k] = al16 && bs >= 0 && bs + 16 <= wb;
+            if (plain[k]) stg[k] = *(const uint4*)(sf + (size_t)sy * g.stride + bs);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < SHB_VPT; k++) {
+        const int i = threadIdx.x + k * 256;
+        if (i >= SHB_NV) continue;
+        uint4 v = stg[k];
+        if (!plain[k]) {
+            const int r = i / SHB_VPR, c = i - r * SHB_VPR;
+            const int sy = d_reflect101(y0 - 1 + r, g.h);
+            const int bs = xb0 - 16 + c * 16;
             u32 w4[4] = {0, 0, 0, 0};
             if (bs + 16 > -3 && bs < wb + 3) { // only bytes within one pixel of the row are ever used
-                for (int k = 0; k < 16; k++) {
-                    const int bx = bs + k;
+                for (int kk = 0; kk < 16; kk++) {
+                    const int bx = bs + kk;
                     // byte bx belongs to pixel floor(bx / 3); reflect the pixel (REFLECT_101), keep the channel
                     const int pxl = bx >= 0 ? bx / 3 : -((2 - bx) / 3);
                     const int ch = bx - pxl * 3;
-                    if (pxl >= -1 && pxl <= g.w) w4[k >> 2] |= (u32)sf[(size_t)sy * g.stride + d_reflect101(pxl, g.w) * 3 + ch] << ((k & 3) * 8);
+                    if (pxl >= -1 && pxl <= g.w) w4[kk >> 2] |= (u32)sf[(size_t)sy * g.stride + d_reflect101(pxl, g.w) * 3 + ch] << ((kk & 3) * 8);
                 }
             }
             v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
         }
-        *(uint4*)&tile[r * SHB_PITCH + c * 16] = v;
+        *(uint4*)&tile[i * 16] = v; // i = r * SHB_VPR + c and SHB_PITCH = 16 * SHB_VPR
     }
+    SH_STAMP(1);
     __syncthreads();
+    SH_STAMP(2);
 
     const int lc = threadIdx.x & 63, rq = threadIdx.x >> 6; // 64 chunks of 16 B x 4 row quads
     const int x0 = xb0 + lc * 16;
@@ -678,7 +712,36 @@ __global__ __launch_bounds__(256) void k_sharpen_box(const u8* __restrict__ src,
         atomicMin(&mm[0], (u32)min(min(red[0], red[1]), min(red[2], red[3])));
         atomicMax(&mm[1], (u32)max(max(red[4], red[5]), max(red[6], red[7])));
     }
+#ifdef SH_TIMING
+    SH_STAMP(3);
+    if (threadIdx.x == 0) {
+        const unsigned int k = atomicAdd(&g_sh_count, 1u);
+        if (k < SH_MAX_STAMPS) {
+            unsigned int hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            g_sh_stamps[k * 5 + 0] = hw;
+            for (int q = 0; q < 4; q++) g_sh_stamps[k * 5 + 1 + q] = sh_t[q];
+        }
+    }
+#endif
 }
+
+#ifdef SH_TIMING
+extern "C" __attribute__((visibility("default"))) int cbv_debug_sharpen_stamps(unsigned long long* out, int cap, int reset)
+{
+    unsigned int n = 0;
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_sh_count), sizeof(n));
+    if (n > SH_MAX_STAMPS) n = SH_MAX_STAMPS;
+    if ((int)n > cap) n = cap;
+    if (out && n) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sh_stamps), (size_t)n * 5 * sizeof(unsigned long long));
+    if (reset) {
+        unsigned int z = 0;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sh_count), &z, sizeof(z));
+    }
+    return (int)n;
+}
+#endif
 
 int launch_sharpen(cbv_ctx* ctx, const u8* src, u8* dst, u32* aux, int tiles, Geom g, const float* k, int batch)
 {
