@@ -69,20 +69,38 @@ __global__ __launch_bounds__(256) void k_squares_preprocess5(const u8* __restric
     if (d.cn == 3) {
         // four pixels (12 bytes, any alignment) per lane and load instruction: the ROI read is bound by the number
         // of memory instructions, not by bytes
-        const int ngx = (w + 3) >> 2;
-        for (int t = threadIdx.x; t < ngx * h; t += 256) {
-            const int y = t / ngx, x0 = (t - y * ngx) << 2;
-            const u8* p = s + (size_t)y * d.stride + 3 * x0;
-            u8* o = g + y * w + x0;
-            if (x0 + 3 < w) {
-                u32 v[3];
-                __builtin_memcpy(v, p, 12);
-                o[0] = (u8)d_gray(v[0] & 255, (v[0] >> 8) & 255, (v[0] >> 16) & 255);
-                o[1] = (u8)d_gray(v[0] >> 24, v[1] & 255, (v[1] >> 8) & 255);
-                o[2] = (u8)d_gray((v[1] >> 16) & 255, v[1] >> 24, v[2] & 255);
-                o[3] = (u8)d_gray((v[2] >> 8) & 255, (v[2] >> 16) & 255, v[2] >> 24);
-            } else {
-                for (int k = 0; x0 + k < w; k++) o[k] = (u8)d_gray(p[3 * k], p[3 * k + 1], p[3 * k + 2]);
+        const int ngx = (w + 3) >> 2, ntask = ngx * h;
+        // four tasks a lane per round, all their loads issued before the first result is stored (a load-compute-
+        // store loop pays one memory latency per iteration)
+        for (int t0 = threadIdx.x; t0 < ntask; t0 += 4 * 256) {
+            u32 v[4][3];
+            int yy[4], xx[4];
+            bool full[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int t = t0 + q * 256;
+                full[q] = false;
+                if (t < ntask) {
+                    yy[q] = t / ngx;
+                    xx[q] = (t - yy[q] * ngx) << 2;
+                    full[q] = xx[q] + 3 < w;
+                    if (full[q]) __builtin_memcpy(v[q], s + (size_t)yy[q] * d.stride + 3 * xx[q], 12);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int t = t0 + q * 256;
+                if (t >= ntask) continue;
+                u8* o = g + yy[q] * w + xx[q];
+                if (full[q]) {
+                    o[0] = (u8)d_gray(v[q][0] & 255, (v[q][0] >> 8) & 255, (v[q][0] >> 16) & 255);
+                    o[1] = (u8)d_gray(v[q][0] >> 24, v[q][1] & 255, (v[q][1] >> 8) & 255);
+                    o[2] = (u8)d_gray((v[q][1] >> 16) & 255, v[q][1] >> 24, v[q][2] & 255);
+                    o[3] = (u8)d_gray((v[q][2] >> 8) & 255, (v[q][2] >> 16) & 255, v[q][2] >> 24);
+                } else {
+                    const u8* p = s + (size_t)yy[q] * d.stride + 3 * xx[q];
+                    for (int k = 0; xx[q] + k < w; k++) o[k] = (u8)d_gray(p[3 * k], p[3 * k + 1], p[3 * k + 2]);
+                }
             }
         }
     } else {
@@ -186,6 +204,7 @@ __global__ __launch_bounds__(256) void k_squares_stats(const SquareDesc* __restr
     for (int k = 0; k < 17; k++) v[k] = 0;
     float zmax = 0.f;
     int nan_seen = 0;
+#pragma unroll 4
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const int gv = g[i];
         const u32 mk = m[i];
