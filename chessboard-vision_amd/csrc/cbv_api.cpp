@@ -1263,9 +1263,6 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
             rc_all = launch_warp(ctx, res, p->g, p->Minv, S, S, cfg.rot180, wdst, S * 3, p->warped_stride, SL.norm_lut, b);
         }
         if (rc_all) break;
-        rc_all = launch_squares_preprocess(ctx, wdst, p->warped_stride, (const SquareDesc*)p->d_descs.p, n, (const int*)p->d_coef.p, 5,
-                                           (u8*)p->d_gray.p + p->plane_total * s0, p->plane_total, b, p->max_px);
-        if (rc_all) break;
         u8* dec = (u8*)p->d_dec.p + (size_t)CBV_MAX_SQUARES * s0;
         u32* work = nullptr;
         cbv_hough_result* hres = nullptr;
@@ -1277,10 +1274,11 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
                 break;
             }
         }
-        rc_all = launch_squares_stats(ctx, (const SquareDesc*)p->d_descs.p, n, (const u8*)p->d_gray.p + p->plane_total * s0, p->plane_total,
-                                      nullptr, p->calibrated ? (const float*)p->d_mean.p : nullptr, p->calibrated ? (const float*)p->d_var.p : nullptr,
-                                      (const u8*)p->d_masks.p, (float)cfg.z_threshold, (cbv_sq_stats*)p->d_stats.p + (size_t)n * s0, b,
-                                      dec, cfg.use_hough, work, hres);
+        rc_all = launch_squares_pre5_stats(ctx, wdst, p->warped_stride, (const SquareDesc*)p->d_descs.p, n,
+                                           (u8*)p->d_gray.p + p->plane_total * s0, p->plane_total,
+                                           p->calibrated ? (const float*)p->d_mean.p : nullptr, p->calibrated ? (const float*)p->d_var.p : nullptr,
+                                           (const u8*)p->d_masks.p, (float)cfg.z_threshold, (cbv_sq_stats*)p->d_stats.p + (size_t)n * s0, b,
+                                           dec, cfg.use_hough, work, hres, p->max_px);
         if (rc_all) break;
         if (cfg.use_hough)
             rc_all = launch_hough(ctx, (const SquareDesc*)p->d_descs.p, n, (const u8*)p->d_gray.p + p->plane_total * s0, p->plane_total,

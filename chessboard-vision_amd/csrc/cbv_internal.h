@@ -210,6 +210,10 @@ struct HoughCfg {
 // as k_squares_stats lists them; a found circle sets bit 0 of the square's `decisions` byte.
 int launch_hough(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, size_t gray_frame_stride, HoughCfg cfg,
                  cbv_hough_result* out, u8* decisions, const u32* work, int batch);
+int launch_squares_pre5_stats(cbv_ctx* ctx, const u8* src, size_t src_frame_stride, const SquareDesc* descs, int n, u8* gray,
+                              size_t gray_frame_stride, const float* mean, const float* var, const u8* masks, float z_thresh,
+                              cbv_sq_stats* out, int batch, u8* decisions, int want_hough, u32* hough_work,
+                              cbv_hough_result* hough_out, int max_px);
 int launch_squares_calibrate(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, float* mean, float* var,
                              float init_var, const u8* select);
 int launch_squares_ema(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, float* mean, float* var,

@@ -181,63 +181,64 @@ __device__ int d_detect_piece(const cbv_sq_stats& st)
 }
 
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_squares_stats(const SquareDesc* __restrict__ descs,
-                                                        const u8* __restrict__ gray, size_t gray_frame_stride,
-                                                        const u8* __restrict__ ref, const float* __restrict__ mean,
-                                                        const float* __restrict__ var, const u8* __restrict__ masks,
-                                                        float z_thresh, cbv_sq_stats* __restrict__ out, int nsq,
-                                                        u8* __restrict__ decisions, int want_hough, u32* __restrict__ hough_work,
-                                                        cbv_hough_result* __restrict__ hough_out)
-{
-    __shared__ u32 acc[20];
-    __shared__ float zm[4];
-    __shared__ int nanf_[1];
-    const SquareDesc d = descs[blockIdx.x];
-    const int n = d.w * d.h;
-    if (threadIdx.x < 20) acc[threadIdx.x] = 0;
-    if (threadIdx.x == 0) nanf_[0] = 0;
-    __syncthreads();
-    const u8* g = gray + (size_t)blockIdx.z * gray_frame_stride + d.plane_off;
-    const u8* m = masks + d.mask_off;
+// per-square statistics, shared by k_squares_stats (planes already in memory) and the fused
+// k_squares_pre5_stats (pixels coming straight out of the blur)
+// ---------------------------------------------------------------------------
+struct SqAccum {
     u32 v[17];
+    float zmax;
+    int nan_seen;
+};
+
+__device__ __forceinline__ void sq_accum_init(SqAccum& A)
+{
 #pragma unroll
-    for (int k = 0; k < 17; k++) v[k] = 0;
-    float zmax = 0.f;
-    int nan_seen = 0;
-#pragma unroll 4
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const int gv = g[i];
-        const u32 mk = m[i];
-        v[0] += gv;
-        v[1] += gv * gv;
-        if (ref) v[2] += (u32)abs(gv - (int)ref[d.plane_off + i]);
-        v[3] += (mk & 1) ? gv : 0;
-        v[4] += (mk & 1);
-        v[5] += (mk & 2) ? gv : 0;
-        v[6] += (mk >> 1) & 1;
+    for (int k = 0; k < 17; k++) A.v[k] = 0;
+    A.zmax = 0.f;
+    A.nan_seen = 0;
+}
+
+__device__ __forceinline__ void sq_accum_px(SqAccum& A, int gv, u32 mk, bool has_ref, int refv, bool has_model, float mu, float va,
+                                            float z_thresh)
+{
+    A.v[0] += gv;
+    A.v[1] += gv * gv;
+    if (has_ref) A.v[2] += (u32)abs(gv - refv);
+    A.v[3] += (mk & 1) ? gv : 0;
+    A.v[4] += (mk & 1);
+    A.v[5] += (mk & 2) ? gv : 0;
+    A.v[6] += (mk >> 1) & 1;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            v[7 + k] += (mk & (4u << k)) ? gv : 0;
-            v[11 + k] += (mk >> (2 + k)) & 1;
-        }
-        if (mean) {
-            // change_detector.py:131-137 in float32: sqrt and division are IEEE-rounded
-            const float sd = __fsqrt_rn(var[d.plane_off + i]);
-            const float df = fabsf((float)gv - mean[d.plane_off + i]);
-            const float z = __fdiv_rn(df, sd);
-            if (z > z_thresh) v[15]++;
-            if (z != z) nan_seen = 1;
-            else zmax = fmaxf(zmax, z);
-        }
+    for (int k = 0; k < 4; k++) {
+        A.v[7 + k] += (mk & (4u << k)) ? gv : 0;
+        A.v[11 + k] += (mk >> (2 + k)) & 1;
     }
+    if (has_model) {
+        // change_detector.py:131-137 in float32: sqrt and division are IEEE-rounded
+        const float sd = __fsqrt_rn(va);
+        const float df = fabsf((float)gv - mu);
+        const float z = __fdiv_rn(df, sd);
+        if (z > z_thresh) A.v[15]++;
+        if (z != z) A.nan_seen = 1;
+        else A.zmax = fmaxf(A.zmax, z);
+    }
+}
+
+// block reduction + the record and the decision byte (thread 0).  acc[20], zm[4], nanf_[1] are LDS, zeroed and
+// synchronised by the caller before any lane gets here.
+__device__ __forceinline__ void sq_accum_finish(SqAccum& A, u32* acc, float* zm, int* nanf_, int n, bool has_model,
+                                                cbv_sq_stats* __restrict__ out, int nsq, u8* __restrict__ decisions,
+                                                int want_hough, u32* __restrict__ hough_work,
+                                                cbv_hough_result* __restrict__ hough_out)
+{
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        u32 s = wave_sum_u32(v[k]);
+        u32 s = wave_sum_u32(A.v[k]);
         if ((threadIdx.x & 63) == 0 && s) atomicAdd(&acc[k], s);
     }
-    zmax = wave_max_f32(zmax);
+    const float zmax = wave_max_f32(A.zmax);
     if ((threadIdx.x & 63) == 0) zm[threadIdx.x >> 6] = zmax;
-    if (nan_seen) nanf_[0] = 1;
+    if (A.nan_seen) nanf_[0] = 1;
     __syncthreads();
     if (threadIdx.x == 0) {
         cbv_sq_stats st;
@@ -273,13 +274,139 @@ __global__ __launch_bounds__(256) void k_squares_stats(const SquareDesc* __restr
                 r.flags = CBV_HOUGH_SKIPPED;
                 hough_out[(size_t)blockIdx.z * CBV_MAX_SQUARES + blockIdx.x] = r;
             }
-            if (mean) {
+            if (has_model) {
                 const double pct = ((double)st.z_count / (double)st.n) * 100.0; // change_detector.py:139 as a Python float
                 if (!(pct < 5.0)) dc |= 2u | (pct > 75.0 ? 8u : (pct > 15.0 ? 4u : 0u));
             }
             decisions[(size_t)blockIdx.z * CBV_MAX_SQUARES + blockIdx.x] = (u8)dc;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_squares_stats(const SquareDesc* __restrict__ descs,
+                                                        const u8* __restrict__ gray, size_t gray_frame_stride,
+                                                        const u8* __restrict__ ref, const float* __restrict__ mean,
+                                                        const float* __restrict__ var, const u8* __restrict__ masks,
+                                                        float z_thresh, cbv_sq_stats* __restrict__ out, int nsq,
+                                                        u8* __restrict__ decisions, int want_hough, u32* __restrict__ hough_work,
+                                                        cbv_hough_result* __restrict__ hough_out)
+{
+    __shared__ u32 acc[20];
+    __shared__ float zm[4];
+    __shared__ int nanf_[1];
+    const SquareDesc d = descs[blockIdx.x];
+    const int n = d.w * d.h;
+    if (threadIdx.x < 20) acc[threadIdx.x] = 0;
+    if (threadIdx.x == 0) nanf_[0] = 0;
+    __syncthreads();
+    const u8* g = gray + (size_t)blockIdx.z * gray_frame_stride + d.plane_off;
+    const u8* m = masks + d.mask_off;
+    SqAccum A;
+    sq_accum_init(A);
+#pragma unroll 4
+    for (int i = threadIdx.x; i < n; i += blockDim.x)
+        sq_accum_px(A, g[i], m[i], ref != nullptr, ref ? (int)ref[d.plane_off + i] : 0, mean != nullptr,
+                    mean ? mean[d.plane_off + i] : 0.f, mean ? var[d.plane_off + i] : 1.f, z_thresh);
+    sq_accum_finish(A, acc, zm, nanf_, n, mean != nullptr, out, nsq, decisions, want_hough, hough_work, hough_out);
+}
+
+// preprocess (k = 5) and statistics of the pipeline in one pass: the statistics are sums over the plane the blur
+// produces, so they are taken as the pixels leave the vertical pass (one launch and one read of the plane less)
+__global__ __launch_bounds__(256) void k_squares_pre5_stats(const u8* __restrict__ src, size_t src_frame_stride,
+                                                             const SquareDesc* __restrict__ descs, u8* __restrict__ gray,
+                                                             size_t gray_frame_stride, const float* __restrict__ mean,
+                                                             const float* __restrict__ var, const u8* __restrict__ masks,
+                                                             float z_thresh, cbv_sq_stats* __restrict__ out, int nsq,
+                                                             u8* __restrict__ decisions, int want_hough,
+                                                             u32* __restrict__ hough_work, cbv_hough_result* __restrict__ hough_out)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    __shared__ u32 acc[20];
+    __shared__ float zm[4];
+    __shared__ int nanf_[1];
+    const SquareDesc d = descs[blockIdx.x];
+    const int w = d.w, h = d.h, n = w * h;
+    u8* g = smem;
+    u16* hb = (u16*)(smem + ((n + 15) & ~15));
+    const u8* s = src + (size_t)blockIdx.z * src_frame_stride + d.src_off;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    if (threadIdx.x < 20) acc[threadIdx.x] = 0;
+    if (threadIdx.x == 0) nanf_[0] = 0;
+    {
+        const int ngx = (w + 3) >> 2, ntask = ngx * h;
+        for (int t0 = threadIdx.x; t0 < ntask; t0 += 4 * 256) {
+            u32 v[4][3];
+            int yy[4], xx[4];
+            bool full[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int t = t0 + q * 256;
+                full[q] = false;
+                if (t < ntask) {
+                    yy[q] = t / ngx;
+                    xx[q] = (t - yy[q] * ngx) << 2;
+                    full[q] = xx[q] + 3 < w;
+                    if (full[q]) __builtin_memcpy(v[q], s + (size_t)yy[q] * d.stride + 3 * xx[q], 12);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int t = t0 + q * 256;
+                if (t >= ntask) continue;
+                u8* o = g + yy[q] * w + xx[q];
+                if (full[q]) {
+                    o[0] = (u8)d_gray(v[q][0] & 255, (v[q][0] >> 8) & 255, (v[q][0] >> 16) & 255);
+                    o[1] = (u8)d_gray(v[q][0] >> 24, v[q][1] & 255, (v[q][1] >> 8) & 255);
+                    o[2] = (u8)d_gray((v[q][1] >> 16) & 255, v[q][1] >> 24, v[q][2] & 255);
+                    o[3] = (u8)d_gray((v[q][2] >> 8) & 255, (v[q][2] >> 16) & 255, v[q][2] >> 24);
+                } else {
+                    const u8* p = s + (size_t)yy[q] * d.stride + 3 * xx[q];
+                    for (int k = 0; xx[q] + k < w; k++) o[k] = (u8)d_gray(p[3 * k], p[3 * k + 1], p[3 * k + 2]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int x = tx; x < w; x += 16) {
+        const int x0 = d_reflect101(x - 2, w), x1 = d_reflect101(x - 1, w), x3 = d_reflect101(x + 1, w), x4 = d_reflect101(x + 2, w);
+        for (int y = ty; y < h; y += 16) {
+            const u8* r = g + y * w;
+            hb[y * w + x] = (u16)(16 * (r[x0] + r[x4]) + 64 * (r[x1] + r[x3]) + 96 * r[x]);
+        }
+    }
+    __syncthreads();
+    u8* outp = gray + (size_t)blockIdx.z * gray_frame_stride + d.plane_off;
+    const u8* m = masks + d.mask_off;
+    const float* mp = mean ? mean + d.plane_off : nullptr;
+    const float* vp = mean ? var + d.plane_off : nullptr;
+    SqAccum A;
+    sq_accum_init(A);
+    for (int y = ty; y < h; y += 16) {
+        const int y0 = d_reflect101(y - 2, h) * w, y1 = d_reflect101(y - 1, h) * w, y3 = d_reflect101(y + 1, h) * w, y4 = d_reflect101(y + 2, h) * w;
+        for (int x = tx; x < w; x += 16) {
+            const u32 a2 = 16u * (hb[y0 + x] + hb[y4 + x]) + 64u * (hb[y1 + x] + hb[y3 + x]) + 96u * hb[y * w + x];
+            const int gv = (int)((a2 + (1u << 15)) >> 16);
+            const int i = y * w + x;
+            outp[i] = (u8)gv;
+            sq_accum_px(A, gv, m[i], false, 0, mp != nullptr, mp ? mp[i] : 0.f, mp ? vp[i] : 1.f, z_thresh);
+        }
+    }
+    sq_accum_finish(A, acc, zm, nanf_, n, mp != nullptr, out, nsq, decisions, want_hough, hough_work, hough_out);
+}
+
+int launch_squares_pre5_stats(cbv_ctx* ctx, const u8* src, size_t src_frame_stride, const SquareDesc* descs, int n, u8* gray,
+                              size_t gray_frame_stride, const float* mean, const float* var, const u8* masks, float z_thresh,
+                              cbv_sq_stats* out, int batch, u8* decisions, int want_hough, u32* hough_work,
+                              cbv_hough_result* hough_out, int max_px)
+{
+    if (max_px <= 0 || max_px > CBV_MAX_SQUARE_DIM * CBV_MAX_SQUARE_DIM) max_px = CBV_MAX_SQUARE_DIM * CBV_MAX_SQUARE_DIM;
+    const size_t lds = (size_t)((max_px + 15) & ~15) + 2 * (size_t)max_px;
+    prof_begin(ctx, CBV_K_SQUARES);
+    hipLaunchKernelGGL(k_squares_pre5_stats, dim3(n, 1, batch), dim3(256), lds, ctx->stream, src, src_frame_stride, descs, gray,
+                       gray_frame_stride, mean, var, masks, z_thresh, out, n, decisions, want_hough, hough_work, hough_out);
+    prof_end(ctx, CBV_K_SQUARES);
+    CBV_HIP(ctx, hipGetLastError());
+    return CBV_OK;
 }
 
 int launch_squares_stats(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, size_t gray_frame_stride,
