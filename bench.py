@@ -89,6 +89,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # rehearsal on a box with fewer GPUs than ranks (never the driver's configuration): CBV_BENCH_BACKEND=gloo lets
+    # several ranks share a device, CBV_BENCH_DEVICE pins the device index
+    backend = os.environ.get("CBV_BENCH_BACKEND", "nccl")
+    if "CBV_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["CBV_BENCH_DEVICE"])
 
     import numpy as np
     import torch
@@ -103,7 +108,7 @@ def main():
         saved = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
+            dist.init_process_group(backend=backend if torch.cuda.is_available() else "gloo")
             dist.barrier()
             torch.cuda.synchronize()
         finally:
@@ -157,7 +162,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         dist.barrier()
