@@ -59,7 +59,7 @@ def _L():
         proto = {
             "cbv_board_create": (vp, []), "cbv_board_destroy": (None, [vp]), "cbv_board_reset": (None, [vp]),
             "cbv_board_set_fen": (i32, [vp, C.c_char_p]), "cbv_board_fen": (i32, [vp, C.c_char_p, i32]),
-            "cbv_board_turn": (i32, [vp]), "cbv_board_piece_at": (i32, [vp, i32]), "cbv_board_occupancy": (u64, [vp]),
+            "cbv_board_turn": (i32, [vp]), "cbv_board_set_turn": (None, [vp, i32]), "cbv_board_piece_at": (i32, [vp, i32]), "cbv_board_occupancy": (u64, [vp]),
             "cbv_board_legal_moves": (i32, [vp, C.POINTER(u16), i32]), "cbv_board_is_legal": (i32, [vp, u16]),
             "cbv_board_is_capture": (i32, [vp, u16]), "cbv_board_is_en_passant": (i32, [vp, u16]),
             "cbv_board_is_check": (i32, [vp]), "cbv_board_push": (i32, [vp, u16]), "cbv_board_pop": (u16, [vp]),
@@ -174,6 +174,10 @@ class Board:
     def turn(self):
         return bool(_L().cbv_board_turn(self._h))
 
+    @turn.setter
+    def turn(self, white):
+        _L().cbv_board_set_turn(self._h, 1 if white else 0)
+
     @property
     def legal_moves(self):
         return LegalMoveGenerator(self)
@@ -209,6 +213,14 @@ class Board:
 
     def push(self, move):
         _L().cbv_board_push(self._h, move._code())
+
+    def push_uci(self, uci):
+        """Parse and play a UCI move; ValueError when it is not legal here (lichess_session.py uses it to sync)."""
+        move = Move.from_uci(uci)
+        if move not in self.legal_moves:
+            raise ValueError("illegal uci: %r in %s" % (uci, self.fen()))
+        self.push(move)
+        return move
 
     def pop(self):
         m = Move._from_code(_L().cbv_board_pop(self._h))

@@ -602,6 +602,10 @@ int cbv_board_fen(const cbv_board* b, char* out, int cap)
     return (int)s.size();
 }
 int cbv_board_turn(const cbv_board* b) { return b ? b->turn : -1; }
+void cbv_board_set_turn(cbv_board* b, int white)
+{
+    if (b) b->turn = white ? 1 : 0;
+}
 int cbv_board_piece_at(const cbv_board* b, int square) { return (b && square >= 0 && square < 64) ? b->sq[square] : 0; }
 uint64_t cbv_board_occupancy(const cbv_board* b)
 {

@@ -45,6 +45,7 @@ CBV_API int cbv_board_set_fen(cbv_board* b, const char* fen);
 CBV_API int cbv_board_fen(const cbv_board* b, char* out, int cap);
 /* board.turn: 1 = white (chess.WHITE is True), 0 = black */
 CBV_API int cbv_board_turn(const cbv_board* b);
+CBV_API void cbv_board_set_turn(cbv_board* b, int white); /* board.turn = chess.WHITE (test_race_condition.py:45) */
 /* board.piece_at(sq): 0 = empty, else piece_type (1 pawn .. 6 king) | 8 when black */
 CBV_API int cbv_board_piece_at(const cbv_board* b, int square);
 /* bit s = a piece stands on square s   (get_board_occupancy, game_state.py:26-38) */

@@ -244,3 +244,16 @@ def test_infer_move_and_stable_tracker():
     # smart scan set of the start position: 32 occupied squares + the (file, 7 - rank) images of ranks 3 and 4
     sq = smart_scan_squares(GameState())
     assert len(sq) == 32 + 16 and (0, 5) in sq and (0, 4) in sq and (0, 2) not in sq
+
+
+def test_board_surface_used_by_the_session_layer():
+    """push_uci (lichess_session.py sync), assignable turn (test_race_condition.py:45), Piece symbols, str()."""
+    b = chess.Board()
+    assert b.push_uci("e2e4").uci() == "e2e4" and b.turn == chess.BLACK
+    with pytest.raises(ValueError):
+        b.push_uci("e2e4")
+    b.turn = chess.WHITE
+    assert b.turn == chess.WHITE and b.fen().split()[1] == "w"
+    assert b.piece_at(chess.E4).symbol() == "P" and b.piece_at(chess.E8).symbol() == "k" and b.piece_at(chess.E3) is None
+    assert str(chess.Board()).splitlines()[0] == "r n b q k b n r" and len(chess.SQUARES) == 64
+    assert chess.square_name(chess.square(4, 3)) == "e4" and chess.parse_square("h8") == 63
