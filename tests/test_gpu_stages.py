@@ -478,3 +478,49 @@ def test_bilateral_rejects_diameters_beyond_the_tile_halo(gpu_ctx):
     out = np.empty_like(f)
     with pytest.raises(RuntimeError, match="radius"):
         gpu_ctx.check(gpu_ctx.lib.cbv_reduce_noise(gpu_ctx.h, f.ctypes.data, 32, 32, 96, 15, 10.0, 10.0, out.ctypes.data, 96))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_randomised_enhancement_parameters(gpu_ctx, oracle, seed):
+    """Seeded sweep over what the fixed cases do not reach: random colour profiles (both modes, out-of-range hue
+    shifts, contrast that folds through convertScaleAbs' abs), CLAHE clip limits from 'no clipping' to heavy, tile
+    grids that do not divide the image, odd image sizes, float sharpen kernels — each stage and the whole chain."""
+    from chessboard_vision_amd.frame_enhancer import ImageEnhancer
+    rng = np.random.default_rng(1000 + seed)
+    w, h = int(rng.integers(65, 400)), int(rng.integers(49, 300))
+    f = random_frame(w, h, 77 + seed, smooth=bool(seed % 2))
+    prof = {"hue_shift": float(rng.uniform(-400, 400)), "sat_scale": float(rng.uniform(0, 3)), "val_scale": float(rng.uniform(0, 3)),
+            "contrast": float(rng.uniform(-2, 3)), "brightness": float(rng.uniform(-200, 200)), "radical_mode": int(seed % 3 == 0),
+            "target_hue": float(rng.integers(0, 180)), "hue_window": float(rng.uniform(0, 90))}
+    clip = [0.0, 0.5, 1.0, 2.0, 3.0, 8.0, 40.0][seed % 7]
+    tiles = (int(rng.integers(1, 10)), int(rng.integers(1, 10)))
+    e = ImageEnhancer(clahe_clip_limit=clip, tile_grid_size=tiles)
+    e.profile = prof
+    assert_same(e.apply_color_profile(f), oracle.apply_color_profile(f, prof), "profile %r" % prof)
+    assert_same(e.correct_lighting(f), oracle.correct_lighting(f, clip, tiles), "clahe %r %r %dx%d" % (clip, tiles, w, h))
+    if seed % 2:
+        k = rng.normal(0, 1, (3, 3)).astype(np.float32)
+        e.sharpen_kernel = k
+    else:
+        k = e.sharpen_kernel
+    assert_same(e.sharpen(f), oracle.filter3x3(f, np.asarray(k, np.float32)), "sharpen")
+    assert_same(e.process_pipeline(f), oracle.process_pipeline(f, prof, clip, tiles, np.asarray(k, np.float32)), "chain")
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_randomised_warps(gpu_ctx, oracle, seed):
+    """Random quadrilaterals (inside, partly outside, nearly degenerate, mirrored), random destination sizes and both
+    orientations: coordinates follow the 64 x 16 block scheme in double, so every output byte must match."""
+    from chessboard_vision_amd.board_detection import get_perspective_transform, warp_perspective
+    rng = np.random.default_rng(500 + seed)
+    w, h = int(rng.integers(40, 500)), int(rng.integers(30, 400))
+    f = random_frame(w, h, 300 + seed, smooth=bool(seed & 1))
+    base = np.float32([[0, 0], [w, 0], [0, h], [w, h]])
+    pts = base + rng.uniform(-0.35, 0.35, (4, 2)).astype(np.float32) * np.float32([w, h])
+    if seed % 4 == 3:
+        pts = pts[[1, 0, 3, 2]]            # mirrored quad
+    dw, dh = int(rng.integers(1, 700)), int(rng.integers(1, 700))
+    M = get_perspective_transform(pts, np.float32([[0, 0], [dw, 0], [0, dh], [dw, dh]]))
+    want = oracle.warp_perspective(f, M, (dw, dh))
+    assert_same(warp_perspective(f, M, (dw, dh)), want, "warp %dx%d -> %dx%d" % (w, h, dw, dh))
+    assert_same(warp_perspective(f, M, (dw, dh), rot180=True), oracle.rotate180(want), "warp + rot180")
