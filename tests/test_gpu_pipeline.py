@@ -392,3 +392,49 @@ def test_stream_to_moves_end_to_end(gpu_ctx):
     for k, (i, _) in enumerate(moves):
         assert (k + 1) * fpp + 19 <= i < (k + 2) * fpp + 24, (k, i)
     assert gs.get_fen().startswith("r1bqkbnr/1ppp1ppp/p1n5/1B2p3/4P3/5N2/PPPP1PPP/RNBQK2R w KQkq -")
+
+
+def test_temporal_logic_on_random_board_sequences(gpu_ctx, oracle):
+    """The scan kernel and the device NoiseHandler against the restated host logic on boards that do NOT follow a game:
+    pieces appear and vanish at random, a 'hand' flips a dozen squares for a few frames, quiet stretches let the
+    5-frame majority and the conditional reference refresh settle.  Every per-frame set must match."""
+    from chessboard_vision_amd.grid_extractor import GridExtractor
+    from chessboard_vision_amd.noise_handler import NoiseHandler
+    from chessboard_vision_amd.stream import BoardPipeline, bits_to_positions
+    from helpers import oracle_scene
+    from ref_logic import RefPieceDetector
+    rng = np.random.default_rng(2024)
+    n = 36
+    pts = S.scaled_corners(W, H)
+    Hinv = oracle.get_perspective_transform(pts, S.BOARD_UNIT_QUAD)
+    board = S.board_array(S.position_after(0)).copy()
+    frames, boards = [], []
+    for i in range(n):
+        if i % 3 == 2:                                   # a few random squares change
+            for sq in rng.integers(0, 64, int(rng.integers(1, 4))):
+                board[sq] = 0 if board[sq] else int(rng.integers(1, 3))
+        b = board.copy()
+        if 14 <= i < 18:                                 # a hand: many squares look different for four frames
+            for sq in rng.choice(64, 14, replace=False):
+                b[sq] = 0 if b[sq] else 2
+        boards.append(b)
+        frames.append(oracle.synth_frame(S.frame_seed(5, i), W, H, Hinv, b, oracle_scene("normal")))
+    p = BoardPipeline(W, H, n)
+    p.configure(pts, profile={}, chunk=7, lanes=2, keep_enhanced=True)
+    for i, f in enumerate(frames):
+        p.upload(i, f)
+    p.run(0, 20)                                         # two runs: the temporal state must carry over
+    p.run(20, n - 20)
+    res, noise = p.results(0, n), p.noise_results(0, n)
+    det, nh, ge = RefPieceDetector(hough={}), NoiseHandler(), GridExtractor()
+    for i in range(n):
+        warped, _, _ = oracle.warp_image(oracle.process_pipeline(frames[i], {}), pts)
+        r, vis = det.detect_all_pieces(ge.split_board(warped))
+        want_stable = {pos for pos, info in r.items() if info["has_piece"]}
+        want_raw = {pos for pos, info in det.cached_results.items() if info["has_piece"]}
+        assert bits_to_positions(res[i].visual_changes, p.rois_rc) == set(vis), i
+        assert bits_to_positions(res[i].raw_occupied, p.rois_rc) == want_raw, i
+        assert bits_to_positions(res[i].stable_occupied, p.rois_rc) == want_stable, i
+        state, data = nh.process(set(vis))
+        assert noise[i][0] == state and noise[i][1] == data, (i, noise[i], (state, data))
+    assert any(len(bits_to_positions(r.visual_changes, p.rois_rc)) > 8 for r in res[14:18]), "the hand must be visible"
