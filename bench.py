@@ -78,7 +78,7 @@ def main():
     ap.add_argument("--frames", type=int, default=512, help="frames in flight per GPU")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--chunk", type=int, default=64, help="frames per kernel launch (0 = library default 32)")
     ap.add_argument("--lanes", type=int, default=0, help="HIP streams per GPU the chunks are spread over (0 = library default)")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-profile-pass", action="store_true")
