@@ -917,7 +917,8 @@ struct cbv_pipeline {
     u8* enhanced = nullptr; // [max_frames] when keep_enhanced
     u8* warped = nullptr;   // [max_frames][S][S][3]
     size_t warped_stride = 0;
-    DevBuf d_descs, d_masks, d_gray, d_stats, d_ref, d_state, d_results, d_flags, d_dec, d_coef, d_synth, d_mean, d_var, d_noise, d_noise_state, d_hough;
+    DevBuf d_descs, d_masks, d_gray, d_stats, d_ref, d_state, d_results, d_flags, d_dec, d_coef, d_synth, d_mean, d_var, d_noise, d_noise_state, d_hough, d_check;
+    bool has_check = false; // squares_to_check masks were set
     HoughCfg hough_cfg;
     bool calibrated = false;
     std::vector<SquareDesc> descs;
@@ -1004,7 +1005,7 @@ extern "C" void cbv_pipeline_destroy(cbv_pipeline* p)
     if (p->frames) (void)hipFree(p->frames);
     if (p->enhanced) (void)hipFree(p->enhanced);
     if (p->warped) (void)hipFree(p->warped);
-    DevBuf* bufs[] = {&p->d_descs, &p->d_masks, &p->d_gray, &p->d_stats, &p->d_ref, &p->d_state, &p->d_results, &p->d_flags, &p->d_dec, &p->d_noise, &p->d_noise_state, &p->d_coef, &p->d_synth, &p->d_mean, &p->d_var, &p->d_hough};
+    DevBuf* bufs[] = {&p->d_descs, &p->d_masks, &p->d_gray, &p->d_stats, &p->d_ref, &p->d_state, &p->d_results, &p->d_flags, &p->d_dec, &p->d_noise, &p->d_noise_state, &p->d_coef, &p->d_synth, &p->d_mean, &p->d_var, &p->d_hough, &p->d_check};
     for (auto b : bufs) dev_free(b);
     delete p;
 }
@@ -1097,6 +1098,9 @@ extern "C" int cbv_pipeline_configure(cbv_pipeline* p, const cbv_pipeline_config
     }
     RC(dev_ensure(ctx, &p->d_noise, sizeof(cbv_noise_result) * p->max_frames));
     RC(dev_ensure(ctx, &p->d_noise_state, sizeof(cbv_noise_state)));
+    RC(dev_ensure(ctx, &p->d_check, sizeof(u64) * p->max_frames));
+    CBV_HIP(ctx, hipMemset(p->d_check.p, 0, sizeof(u64) * p->max_frames));
+    p->has_check = false;
     CBV_HIP(ctx, hipMemset(p->d_noise_state.p, 0, sizeof(cbv_noise_state)));
     int coef[32] = {0};
     build_gaussian_q8(5, coef);
@@ -1323,7 +1327,8 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
     sp.thr_int = (int)cfg.change_threshold;
     RC(launch_scan(ctx, (const SquareDesc*)p->d_descs.p, sp, (const u8*)p->d_gray.p + p->plane_total * slot0, p->plane_total,
                    (const u8*)p->d_dec.p + (size_t)CBV_MAX_SQUARES * slot0, (u8*)p->d_ref.p, (ScanState*)p->d_state.p,
-                   (u8*)p->d_flags.p + (size_t)CBV_MAX_SQUARES * slot0, (cbv_frame_result*)p->d_results.p + slot0, count));
+                   (u8*)p->d_flags.p + (size_t)CBV_MAX_SQUARES * slot0, (cbv_frame_result*)p->d_results.p + slot0, count,
+                   p->has_check ? (const u64*)p->d_check.p + slot0 : nullptr));
     // NoiseHandler on the frames' visual_changes sets (game_session.py:165)
     RC(launch_noise(ctx, &((const cbv_frame_result*)p->d_results.p + slot0)->visual_changes, sizeof(cbv_frame_result) / 8, count,
                     (cbv_noise_state*)p->d_noise_state.p, (cbv_noise_result*)p->d_noise.p + slot0));
@@ -1331,6 +1336,20 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
     p->scan_pending = true;
     p->scan_s0 = slot0;
     p->scan_cnt = count;
+    return CBV_OK;
+}
+
+extern "C" int cbv_pipeline_set_check_squares(cbv_pipeline* p, int slot0, int count, const uint64_t* roi_masks)
+{
+    if (!p || !p->configured || slot0 < 0 || count <= 0 || slot0 + count > p->max_frames) return CBV_ERR_ARG;
+    cbv_ctx* ctx = p->ctx;
+    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    RC(join_scan(p)); // the last run's scan may still read the masks
+    if (roi_masks) {
+        CBV_HIP(ctx, hipMemcpyAsync((u64*)p->d_check.p + slot0, roi_masks, sizeof(u64) * count, hipMemcpyHostToDevice, ctx->stream));
+        CBV_HIP(ctx, hipStreamSynchronize(ctx->stream)); // the caller's buffer may go away
+        p->has_check = true;
+    } else CBV_HIP(ctx, hipMemsetAsync((u64*)p->d_check.p + slot0, 0, sizeof(u64) * count, ctx->stream));
     return CBV_OK;
 }
 

@@ -506,7 +506,7 @@ template <int VPT, int SCAN_DEPTH>
 __device__ __forceinline__ void scan_body(const SquareDesc d, const ScanParams sp, const u8* __restrict__ gray,
                                           size_t gray_frame_stride, const u8* __restrict__ decisions,
                                           u8* __restrict__ ref, ScanState* __restrict__ state,
-                                          u8* __restrict__ flags, int count)
+                                          u8* __restrict__ flags, int count, const u64* __restrict__ check)
 {
     const int sq = blockIdx.x;
     const int n = d.w * d.h;
@@ -523,6 +523,7 @@ __device__ __forceinline__ void scan_body(const SquareDesc d, const ScanParams s
             dst[k] = vi < nvec ? gp[vi] : make_uint4(0, 0, 0, 0); // lanes past the plane must compare equal
         }
         sdst = decisions[(size_t)t * CBV_MAX_SQUARES + sq];
+        if (check) sdst |= (u32)((check[t] >> sq) & 1ull) << 8; // squares_to_check of that frame
     };
 #pragma unroll
     for (int k = 0; k < VPT; k++) {
@@ -561,7 +562,7 @@ __device__ __forceinline__ void scan_body(const SquareDesc d, const ScanParams s
                 if (sp.thr_is_int) changed = (long long)tot > (long long)sp.thr_int * n;
                 else changed = (double)tot / (double)n > sp.change_threshold;
             }
-            const bool should_process = !st.has_cache || changed;
+            const bool should_process = !st.has_cache || changed || (dc & 256u); // piece_detector.py:381-389
             const bool in_changes = sp.with_model && (dc & 2u);
             const bool fresh = (dc & 1u) != 0; // detect_piece on the current square (evaluated by k_squares_stats)
             bool raw;
@@ -605,14 +606,15 @@ __device__ __forceinline__ void scan_body(const SquareDesc d, const ScanParams s
 __global__ __launch_bounds__(64) void k_scan(const SquareDesc* __restrict__ descs, ScanParams sp,
                                                const u8* __restrict__ gray, size_t gray_frame_stride,
                                                const u8* __restrict__ decisions, u8* __restrict__ ref,
-                                               ScanState* __restrict__ state, u8* __restrict__ flags, int count)
+                                               ScanState* __restrict__ state, u8* __restrict__ flags, int count,
+                                               const u64* __restrict__ check)
 {
     const SquareDesc d = descs[blockIdx.x];
     const int nvec = (d.w * d.h + 15) >> 4;
     // squares up to 90 x 90 px: eight 16-byte vectors per lane, planes fetched 4 frames ahead (the chain is
     // latency-bound); up to 128 x 128: sixteen vectors, 2 frames ahead
-    if (nvec <= 512) scan_body<8, 4>(d, sp, gray, gray_frame_stride, decisions, ref, state, flags, count);
-    else scan_body<16, 2>(d, sp, gray, gray_frame_stride, decisions, ref, state, flags, count);
+    if (nvec <= 512) scan_body<8, 4>(d, sp, gray, gray_frame_stride, decisions, ref, state, flags, count, check);
+    else scan_body<16, 2>(d, sp, gray, gray_frame_stride, decisions, ref, state, flags, count, check);
 }
 
 // per-square flag bytes of a frame -> the eight 64-bit square sets of cbv_frame_result
@@ -702,11 +704,12 @@ int launch_noise(cbv_ctx* ctx, const u64* changes, size_t stride_words, int coun
 }
 
 int launch_scan(cbv_ctx* ctx, const SquareDesc* descs, ScanParams sp, const u8* gray, size_t gray_frame_stride,
-                const u8* decisions, u8* ref, ScanState* state, u8* flags, cbv_frame_result* results, int count)
+                const u8* decisions, u8* ref, ScanState* state, u8* flags, cbv_frame_result* results, int count,
+                const u64* check)
 {
     prof_begin(ctx, CBV_K_SCAN);
     hipLaunchKernelGGL(k_scan, dim3(sp.n), dim3(64), 0, ctx->stream, descs, sp, gray, gray_frame_stride, decisions, ref,
-                       state, flags, count);
+                       state, flags, count, check);
     hipLaunchKernelGGL(k_pack_results, dim3((count + 3) / 4), dim3(256), 0, ctx->stream, flags, sp.n, results, count);
     prof_end(ctx, CBV_K_SCAN);
     CBV_HIP(ctx, hipGetLastError());

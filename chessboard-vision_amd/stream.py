@@ -118,6 +118,24 @@ class BoardPipeline:
         sc = N.Scene.from_dict(S.SCENES[scene]) if isinstance(scene, str) else scene
         self.ctx.check(self.ctx.lib.cbv_pipeline_synth(self.h_, slot0, count, N.ptr(seeds), N.ptr(Hinv), N.ptr(boards), sc))
 
+    def set_check_squares(self, slot0, sets, count=None):
+        """`squares_to_check` of detect_all_pieces per frame: a list of {(file, rank)} sets for the slots slot0.. —
+        those squares are evaluated afresh even when unchanged and cached.  `sets=None` clears `count` slots
+        (default: all from slot0)."""
+        if sets is None:
+            n = self.max_frames - slot0 if count is None else count
+            self.ctx.check(self.ctx.lib.cbv_pipeline_set_check_squares(self.h_, slot0, n, None))
+            return
+        roi_of = {(c, 7 - r): i for i, (r, c) in enumerate(self.rois_rc)}
+        masks = np.zeros(len(sets), np.uint64)
+        for k, st in enumerate(sets):
+            m = 0
+            for pos in (st or ()):
+                if pos in roi_of:
+                    m |= 1 << roi_of[pos]
+            masks[k] = m
+        self.ctx.check(self.ctx.lib.cbv_pipeline_set_check_squares(self.h_, slot0, len(sets), N.ptr(masks)))
+
     def reset_state(self):
         self.ctx.check(self.ctx.lib.cbv_pipeline_reset_state(self.h_))
 

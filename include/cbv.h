@@ -332,6 +332,10 @@ CBV_API int cbv_pipeline_reset_state(cbv_pipeline* p);
 /* ChangeDetector.calibrate (change_detector.py:36-47) from a slot that a previous cbv_pipeline_run
  * has processed: mean = its preprocessed squares, variance = cfg.initial_variance. */
 CBV_API int cbv_pipeline_calibrate(cbv_pipeline* p, int slot);
+/* detect_all_pieces' `squares_to_check` (piece_detector.py:348,381-389; game_session.py:130-152): per frame a set of
+ * squares (bit = roi) that are processed even when unchanged and cached.  NULL clears the slots' sets (= None).  The
+ * masks stay with the slots until changed. */
+CBV_API int cbv_pipeline_set_check_squares(cbv_pipeline* p, int slot0, int count, const uint64_t* roi_masks);
 /* enqueue enhance -> warp -> detect for frames [slot0, slot0+count) in stream order; asynchronous */
 CBV_API int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count);
 CBV_API int cbv_pipeline_results(cbv_pipeline* p, int slot0, int count, cbv_frame_result* out);

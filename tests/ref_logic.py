@@ -78,6 +78,7 @@ class RefPieceDetector:
 
     def detect_all_pieces(self, squares, use_smoothing=True, use_delta=True, squares_to_check=None):
         results, visual = {}, set()
+        self.last_processed = set()
         for pos, img in squares.items():
             raw, gray = detect_piece(img, hough=self.hough)
             changed = True
@@ -90,6 +91,8 @@ class RefPieceDetector:
             if not should and (squares_to_check is None or use_delta):
                 if pos not in self.cached_results or changed:
                     should = True
+            if should:
+                self.last_processed.add(pos)
             if should or pos not in self.cached_results:
                 self.cached_results[pos] = raw.copy()
                 raw_result = raw

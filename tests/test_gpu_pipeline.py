@@ -438,3 +438,48 @@ def test_temporal_logic_on_random_board_sequences(gpu_ctx, oracle):
         state, data = nh.process(set(vis))
         assert noise[i][0] == state and noise[i][1] == data, (i, noise[i], (state, data))
     assert any(len(bits_to_positions(r.visual_changes, p.rois_rc)) > 8 for r in res[14:18]), "the hand must be visible"
+
+
+def test_pipeline_squares_to_check(gpu_ctx, oracle):
+    """detect_all_pieces(squares_to_check=...) on the device (game_session.py:130-160 passes such a set on 29 of 30
+    frames): forced squares are processed although unchanged and cached, which also refreshes their reference."""
+    from chessboard_vision_amd.grid_extractor import GridExtractor
+    from chessboard_vision_amd.stream import BoardPipeline, bits_to_positions
+    from ref_logic import RefPieceDetector
+    rng = np.random.default_rng(77)
+    n = 14
+    pts = S.scaled_corners(W, H)
+    frames = [oracle_frame(W, H, "normal", stream_id=2, frame_idx=i, frames_per_ply=3) for i in range(n)]
+    all_pos = [(f, r) for f in range(8) for r in range(8)]
+    sets = []
+    for i in range(n):
+        if i % 5 == 0:
+            sets.append(None)                                          # the full scan frame: squares_to_check=None
+        else:
+            sets.append({all_pos[k] for k in rng.choice(64, int(rng.integers(0, 30)), replace=False)})
+    p = BoardPipeline(W, H, n)
+    p.configure(pts, profile={}, chunk=5)
+    for i, f in enumerate(frames):
+        p.upload(i, f)
+    p.set_check_squares(0, [s if s is not None else set() for s in sets])
+    p.run(0, n)
+    res = p.results(0, n)
+    det, ge = RefPieceDetector(hough={}), GridExtractor()
+    forced_seen = 0
+    for i in range(n):
+        warped, _, _ = oracle.warp_image(oracle.process_pipeline(frames[i], {}), pts)
+        r, vis = det.detect_all_pieces(ge.split_board(warped), squares_to_check=sets[i])
+        assert bits_to_positions(res[i].visual_changes, p.rois_rc) == set(vis), i
+        assert bits_to_positions(res[i].processed, p.rois_rc) == det.last_processed, i
+        assert bits_to_positions(res[i].stable_occupied, p.rois_rc) == {pos for pos, info in r.items() if info["has_piece"]}, i
+        forced_seen += len(det.last_processed - set(vis)) if i else 0
+    assert forced_seen > 20, "forced squares must show up as processed without a visual change"
+    # clearing the masks restores squares_to_check=None for every slot
+    p.set_check_squares(0, None)
+    p.reset_state()
+    p.run(0, n)
+    det2 = RefPieceDetector(hough={})
+    for i in range(n):
+        warped, _, _ = oracle.warp_image(oracle.process_pipeline(frames[i], {}), pts)
+        det2.detect_all_pieces(ge.split_board(warped))
+        assert bits_to_positions(p.results(i, 1)[0].processed, p.rois_rc) == det2.last_processed, i
