@@ -1140,6 +1140,19 @@ extern "C" int cbv_pipeline_calibrate(cbv_pipeline* p, int slot)
     return CBV_OK;
 }
 
+extern "C" int cbv_pipeline_update_references(cbv_pipeline* p, int slot, int reset_noise)
+{
+    if (!p || !p->configured) return CBV_ERR_STATE;
+    cbv_ctx* ctx = p->ctx;
+    if (slot < 0 || slot >= p->max_frames) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_pipeline_update_references: bad slot");
+    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    RC(join_scan(p)); // lanes and scan of the last run
+    RC(launch_scan_update_refs(ctx, (const SquareDesc*)p->d_descs.p, p->cfg.n_rois, (const u8*)p->d_gray.p + p->plane_total * slot,
+                               (u8*)p->d_ref.p, (ScanState*)p->d_state.p));
+    if (reset_noise) CBV_HIP(ctx, hipMemsetAsync(p->d_noise_state.p, 0, sizeof(cbv_noise_state), ctx->stream)); // NoiseHandler.reset()
+    return CBV_OK;
+}
+
 extern "C" int cbv_pipeline_upload(cbv_pipeline* p, int slot, const uint8_t* bgr, int stride)
 {
     if (!p || !bgr || slot < 0 || slot >= p->max_frames || stride < p->w * 3) return CBV_ERR_ARG;

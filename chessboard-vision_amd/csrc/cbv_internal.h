@@ -236,6 +236,7 @@ struct ScanParams {
 struct ScanState {       // per square, device resident
     u32 has_ref, has_cache, cached_raw, hist_len, hist_bits;
 };
+int launch_scan_update_refs(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, u8* ref, ScanState* state);
 int launch_noise(cbv_ctx* ctx, const u64* changes, size_t stride_words, int count, cbv_noise_state* state, cbv_noise_result* out);
 int launch_scan(cbv_ctx* ctx, const SquareDesc* descs, ScanParams sp, const u8* gray, size_t gray_frame_stride,
                 const u8* decisions, u8* ref, ScanState* state, u8* flags, cbv_frame_result* results, int count,

@@ -466,6 +466,27 @@ __global__ void k_squares_set_ref(const SquareDesc* __restrict__ descs, const u8
     for (int i = threadIdx.x; i < d.w * d.h; i += blockDim.x) ref[d.plane_off + i] = gray[d.plane_off + i];
 }
 
+// PieceDetector.update_references (piece_detector.py:447-453) on the scan state: reference = the slot's plane,
+// cached results cleared, detection history kept
+__global__ void k_scan_update_refs(const SquareDesc* __restrict__ descs, const u8* __restrict__ gray, u8* __restrict__ ref,
+                                   ScanState* __restrict__ state)
+{
+    const SquareDesc d = descs[blockIdx.x];
+    for (int i = threadIdx.x; i < d.w * d.h; i += blockDim.x) ref[d.plane_off + i] = gray[d.plane_off + i];
+    if (threadIdx.x == 0) {
+        state[blockIdx.x].has_ref = 1;
+        state[blockIdx.x].has_cache = 0;
+        state[blockIdx.x].cached_raw = 0;
+    }
+}
+
+int launch_scan_update_refs(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, u8* ref, ScanState* state)
+{
+    hipLaunchKernelGGL(k_scan_update_refs, dim3(n), dim3(256), 0, ctx->stream, descs, gray, ref, state);
+    CBV_HIP(ctx, hipGetLastError());
+    return CBV_OK;
+}
+
 int launch_squares_calibrate(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, float* mean, float* var,
                              float init_var, const u8* select)
 {

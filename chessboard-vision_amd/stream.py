@@ -136,6 +136,11 @@ class BoardPipeline:
             masks[k] = m
         self.ctx.check(self.ctx.lib.cbv_pipeline_set_check_squares(self.h_, slot0, len(sets), N.ptr(masks)))
 
+    def update_references(self, slot, reset_noise=False):
+        """PieceDetector.update_references with the squares of a processed slot (and NoiseHandler.reset() when
+        `reset_noise`): what the session does right after it accepted a move (game_session.py:219-223)."""
+        self.ctx.check(self.ctx.lib.cbv_pipeline_update_references(self.h_, slot, 1 if reset_noise else 0))
+
     def reset_state(self):
         self.ctx.check(self.ctx.lib.cbv_pipeline_reset_state(self.h_))
 

@@ -336,6 +336,10 @@ CBV_API int cbv_pipeline_calibrate(cbv_pipeline* p, int slot);
  * squares (bit = roi) that are processed even when unchanged and cached.  NULL clears the slots' sets (= None).  The
  * masks stay with the slots until changed. */
 CBV_API int cbv_pipeline_set_check_squares(cbv_pipeline* p, int slot0, int count, const uint64_t* roi_masks);
+/* What the session does after it accepted a move (game_session.py:219-223): PieceDetector.update_references with the
+ * squares of an already processed slot (reference = that frame, cached results cleared, history kept) and, when
+ * reset_noise, NoiseHandler.reset(). */
+CBV_API int cbv_pipeline_update_references(cbv_pipeline* p, int slot, int reset_noise);
 /* enqueue enhance -> warp -> detect for frames [slot0, slot0+count) in stream order; asynchronous */
 CBV_API int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count);
 CBV_API int cbv_pipeline_results(cbv_pipeline* p, int slot0, int count, cbv_frame_result* out);

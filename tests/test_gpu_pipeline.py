@@ -483,3 +483,38 @@ def test_pipeline_squares_to_check(gpu_ctx, oracle):
         warped, _, _ = oracle.warp_image(oracle.process_pipeline(frames[i], {}), pts)
         det2.detect_all_pieces(ge.split_board(warped))
         assert bits_to_positions(p.results(i, 1)[0].processed, p.rois_rc) == det2.last_processed, i
+
+
+def test_pipeline_update_references_mid_stream(gpu_ctx, oracle):
+    """game_session.py:219-223 on the device: after frame k the references are replaced by frame k's squares and the
+    cache is cleared (history kept), the noise handler is reset; the following frames must match the host logic doing
+    the same."""
+    from chessboard_vision_amd.grid_extractor import GridExtractor
+    from chessboard_vision_amd.noise_handler import NoiseHandler
+    from chessboard_vision_amd.stream import BoardPipeline, bits_to_positions
+    from ref_logic import RefPieceDetector
+    n, k = 16, 8
+    pts = S.scaled_corners(W, H)
+    frames = [oracle_frame(W, H, "normal", stream_id=4, frame_idx=i, frames_per_ply=3) for i in range(n)]
+    p = BoardPipeline(W, H, n)
+    p.configure(pts, profile={}, chunk=4)
+    for i, f in enumerate(frames):
+        p.upload(i, f)
+    p.run(0, k + 1)
+    p.update_references(k, reset_noise=True)
+    p.run(k + 1, n - k - 1)
+    res, noise = p.results(0, n), p.noise_results(0, n)
+    det, nh, ge = RefPieceDetector(hough={}), NoiseHandler(), GridExtractor()
+    for i in range(n):
+        warped, _, _ = oracle.warp_image(oracle.process_pipeline(frames[i], {}), pts)
+        sq = ge.split_board(warped)
+        r, vis = det.detect_all_pieces(sq)
+        state, data = nh.process(set(vis))
+        assert bits_to_positions(res[i].visual_changes, p.rois_rc) == set(vis), i
+        assert bits_to_positions(res[i].processed, p.rois_rc) == det.last_processed, i
+        assert bits_to_positions(res[i].stable_occupied, p.rois_rc) == {pos for pos, info in r.items() if info["has_piece"]}, i
+        assert noise[i] == (state, data), i
+        if i == k:
+            det.update_references(sq)
+            nh.reset()
+    assert len(bits_to_positions(res[k + 1].processed, p.rois_rc)) == 64, "cleared cache: everything is processed again"
