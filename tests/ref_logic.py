@@ -76,6 +76,18 @@ class RefPieceDetector:
             self.reference_squares[pos] = O.square_preprocess(img, 5)
         self.cached_results.clear()
 
+    def calibrate_reference(self, squares):
+        self.reference_squares.clear()
+        self.cached_results.clear()
+        for pos, img in squares.items():
+            res, gray = detect_piece(img, hough=self.hough)
+            self.reference_squares[pos] = gray
+            self.cached_results[pos] = res
+
+    def get_occupied_squares(self, squares, use_smoothing=True):
+        results, _ = self.detect_all_pieces(squares, use_smoothing)
+        return {pos for pos, info in results.items() if info["has_piece"]}
+
     def detect_all_pieces(self, squares, use_smoothing=True, use_delta=True, squares_to_check=None):
         results, visual = {}, set()
         self.last_processed = set()
@@ -130,6 +142,24 @@ class RefChangeDetector:
             self.means[pos] = g.astype(np.float32)
             self.variances[pos] = np.full(g.shape, self.initial_variance, dtype=np.float32)
         self.is_calibrated = True
+
+    def set_focus_squares(self, squares):
+        self.focus_squares = set(squares)
+
+    def clear_focus(self):
+        self.focus_squares = set()
+
+    def get_focus_count(self):
+        return len(self.focus_squares) if self.focus_squares else 64
+
+    def detect_changes(self, squares):
+        return {p: v["pct_changed"] for p, v in self.detect_changes_detailed(squares).items() if v["intensity"] in ("PARCIAL", "TOTAL")}
+
+    def classify_hand_pattern(self, detailed):
+        n = len(detailed)
+        if sum(1 for v in detailed.values() if v["intensity"] == "TOTAL") >= 2 or n >= 4 or n > 2:
+            return {"is_hand": True, "is_move": False, "move_candidates": set()}
+        return {"is_hand": False, "is_move": n == 2, "move_candidates": set(detailed.keys())}
 
     def update_all_references(self, squares):
         if not self.is_calibrated:
