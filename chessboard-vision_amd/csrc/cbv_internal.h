@@ -49,11 +49,17 @@ struct ProfileTabs {
     float v_f[256];    // vmap[v] * (1/255)
 };
 
+#define CBV_BL_MAXCLS 10  // distinct dy^2 + dx^2 inside a disc of radius <= 4
 struct BilateralTabs {
     float color_w[768];
     float space_w[128];
     signed char dy[128], dx[128];
     int maxk, radius;
+    // w = space_w * color_w as ONE table lookup: taps with the same dy^2 + dx^2 share a space weight ("class"), and
+    // folded[c][i] = space_w(class c) * color_w[i] is the very float product the filter would form (one IEEE multiply)
+    float folded[CBV_BL_MAXCLS][768];
+    int tap_off[9][16];  // [dy + radius][dx + radius]: class * 768 (word offset into folded), -1 outside the disc
+    int ncls;
 };
 
 void build_static_tabs(StaticTabs* t);

@@ -151,6 +151,24 @@ int build_bilateral_tabs(int d, double sigma_color, double sigma_space, Bilatera
         }
     t->maxk = maxk;
     t->radius = radius;
+    // folded tables (k_bilateral.hip): one per distinct squared distance
+    t->ncls = 0;
+    for (int i = 0; i < 9; i++)
+        for (int j = 0; j < 16; j++) t->tap_off[i][j] = -1;
+    if (radius <= 4) {
+        int r2_of_cls[CBV_BL_MAXCLS];
+        for (int k = 0; k < maxk; k++) {
+            const int r2 = t->dy[k] * t->dy[k] + t->dx[k] * t->dx[k];
+            int c = 0;
+            while (c < t->ncls && r2_of_cls[c] != r2) c++;
+            if (c == t->ncls) {
+                if (t->ncls == CBV_BL_MAXCLS) return -1;
+                r2_of_cls[t->ncls++] = r2;
+                for (int i = 0; i < 768; i++) t->folded[c][i] = t->space_w[k] * t->color_w[i];  // float * float, rounded once
+            }
+            t->tap_off[t->dy[k] + radius][t->dx[k] + radius] = c * 768;
+        }
+    }
     return 0;
 }
 

@@ -2,25 +2,34 @@
 //
 // VALU/LDS-bound stencil (49 taps at d = 9), not an HBM-bound one.  Structure:
 //   - persistent workgroups of 1024 lanes (16 waves = 4 per SIMD, <= 128 VGPRs),
-//     one per CU, each walking 64x64-pixel tiles; consecutive tiles of one XCD
+//     one per CU, each walking 128x64-pixel tiles; consecutive tiles of one XCD
 //     are neighbours, so halo rows are re-read from that XCD's L2;
 //   - the tile (+4 px halo, REFLECT_101 at the image border) sits in LDS as
 //     packed BGRx dwords: |db|+|dg|+|dr| is ONE v_sad_u8; the next tile is
 //     prefetched into registers while the current one is filtered;
-//   - the 766-entry colour-weight table is replicated 32x in LDS with the copy
-//     index in the bank bits (entry i of copy c at word 32 i + c, c = lane & 31):
-//     every lane of a half-wave reads its own bank, so the data-dependent
-//     gather is conflict-free (the first version lost 60 % of its LDS cycles to
-//     bank conflicts);
+//   - the tap weight w = space * colour is ONE table lookup: taps with the same
+//     dy^2 + dx^2 share their space weight, so there are only 10 distinct space
+//     weights at d = 9, and folded[class][sad] (10 x 766 floats, 30 KB, built on
+//     the host with the same single float multiply) replaces the colour-table
+//     lookup AND the multiply.  The class offset rides in v_sad_u8's accumulator
+//     operand (an SGPR), the byte address is one full-rate shift: per tap and
+//     output 6 vector ops (sad, lshl, 3 fma, add) instead of 8.
+//     The table is NOT replicated per bank any more (round 1 kept 32 copies of
+//     the colour table, 98 KB, to make the gather conflict-free): lanes of a
+//     half-wave read neighbouring pixels of one row at one tap, whose colour
+//     distances are close, identical addresses broadcast, and addresses less
+//     than 32 entries apart fall into different banks, so conflicts only arise
+//     between lanes whose distances differ by a multiple of 32
+//     (profiles/r02/sq_counters.txt has the measured conflict rate);
 //   - each lane owns a 4-pixel strip on TWO adjacent rows; per tap row it reads
 //     12 packed pixels with three aligned ds_read_b128 and converts them to
 //     float once for all eight outputs (v_cvt_f32_ubyte is a half-rate op on
 //     gfx950, like v_sad_u8; only f32 add/mul and simple integer ops are full
 //     rate — tools/ubench_valu.hip);
-//   - the LUT address (sad << 7) | (lane & 31) << 2 is ONE v_alignbit_b32;
 //   - taps are accumulated per output in row-major (dy, dx) order exactly like
-//     OpenCV's FMA3-dispatched body: w = space * colour (mul), sum = fma(px, w, sum),
-//     wsum += w: bit-equal to the oracle.
+//     OpenCV's FMA3-dispatched body: w = space * colour (one rounding, here done
+//     when the table is built), sum = fma(px, w, sum), wsum += w: bit-equal to
+//     the oracle.
 #include "cbv_device.h"
 
 #define BL_TW 128        // tile width in pixels (32 strips of 4)
@@ -28,7 +37,7 @@
 #define BL_HALO 4        // halo in pixels (radius <= 4; 4 keeps ds_read_b128 aligned)
 #define BL_PITCH (BL_TW + 2 * BL_HALO)
 #define BL_THREADS 1024
-#define BL_LUT_WORDS (768 * 32)
+#define BL_LUT_WORDS (CBV_BL_MAXCLS * 768)
 
 __host__ __device__ constexpr int bl_row_reach(int R, int dy)
 {
@@ -42,22 +51,16 @@ __global__ __launch_bounds__(BL_THREADS) void k_bilateral(const u8* __restrict__
                                                            const BilateralTabs* __restrict__ bt, int tiles_xn,
                                                            int tiles_yn, int batch)
 {
-    // static LDS (137.9 KB): compile-time addresses let the LUT gather use the ds_read immediate offset
-    // instead of a per-lookup v_add of the dynamic-LDS base
-    __shared__ __attribute__((aligned(16))) float cw[BL_LUT_WORDS];              // [768][32]
+    // static LDS (69 KB): compile-time addresses let the table gather use the ds_read immediate offset
+    __shared__ __attribute__((aligned(16))) float fw[BL_LUT_WORDS];              // [class][768] folded weights
     __shared__ __attribute__((aligned(16))) u32 tile[(BL_TH + 2 * R) * BL_PITCH];
-    __shared__ float sw2d[96];                                                  // [2R+1][9] space weights by (dy, dx)
-    __shared__ int reach[16];                                                   // [2R+1] half-width of the disc per row
     constexpr int ROWS = BL_TH + 2 * R;
     constexpr int GROUPS = BL_PITCH / 4;                        // 4-pixel groups per tile row
     constexpr int NG = ROWS * GROUPS;                           // groups per tile (<= 2448)
     constexpr int GPT = (NG + BL_THREADS - 1) / BL_THREADS;     // groups per thread (3)
 
     const int tid = threadIdx.x;
-    const int lane32 = tid & 31;
-    for (int i = tid; i < BL_LUT_WORDS; i += BL_THREADS) cw[i] = bt->color_w[i >> 5];
-    if (tid < bt->maxk) sw2d[(bt->dy[tid] + R) * 9 + bt->dx[tid] + R] = bt->space_w[tid];
-    if (tid <= 2 * R) reach[tid] = bl_row_reach(R, tid - R);
+    for (int i = tid; i < bt->ncls * 768; i += BL_THREADS) fw[i] = (&bt->folded[0][0])[i];
 
     const int tiles_per_frame = tiles_xn * tiles_yn;
     const int ntiles = tiles_per_frame * batch;
@@ -153,7 +156,6 @@ __global__ __launch_bounds__(BL_THREADS) void k_bilateral(const u8* __restrict__
                 sb[a][o] = sg[a][o] = sr[a][o] = sw[a][o] = 0.f;
                 ctr[a][o] = tile[(ly + a + R) * BL_PITCH + BL_HALO + sx * 4 + o];
             }
-        const u32 lane_hi = (u32)lane32 << 27; // v_alignbit(sad, lane_hi, 25) = (sad << 7) | (lane32 << 2)
         // One tile row per iteration, NOT unrolled (a fully unrolled body makes hipcc schedule ~250
         // live registers).  Tile row ly + i is tap row dy = i - R of output row a and dy = i - 1 - R of
         // output row b; every output still sees its taps in ascending (dy, dx) order.
@@ -162,6 +164,14 @@ __global__ __launch_bounds__(BL_THREADS) void k_bilateral(const u8* __restrict__
         for (int i = 0; i <= 2 * R + 1; i++) {
             const uint4* rowp = (const uint4*)(rowp0 + i * BL_PITCH);
             const uint4 q0 = rowp[0], q1 = rowp[1], q2 = rowp[2];
+            // table offsets of this row's taps for both output rows: wave-uniform scalar loads (-1 = outside the disc)
+            int off[2][2 * R + 1];
+#pragma unroll
+            for (int a = 0; a < 2; a++) {
+                const int dyi = min(max(i - a, 0), 2 * R);
+#pragma unroll
+                for (int d = 0; d <= 2 * R; d++) off[a][d] = bt->tap_off[dyi][d];
+            }
             const u32 p[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
             float fb[12], fg[12], fr[12];
 #pragma unroll
@@ -174,17 +184,16 @@ __global__ __launch_bounds__(BL_THREADS) void k_bilateral(const u8* __restrict__
             for (int a = 0; a < 2; a++) {
                 const int dyi = i - a; // tap-row index of output row a (0 .. 2R), wave-uniform
                 if (dyi < 0 || dyi > 2 * R) continue;
-                const int rx = __builtin_amdgcn_readfirstlane(reach[dyi]);
 #pragma unroll
                 for (int dx = -R; dx <= R; dx++) {
-                    if (dx < -rx || dx > rx) continue; // scalar branch
-                    const float spw = sw2d[dyi * 9 + dx + R];
+                    const int toff = off[a][dx + R];
+                    if (toff < 0) continue; // scalar branch
 #pragma unroll
                     for (int o = 0; o < 4; o++) {
                         const int j = o + 4 + dx;
-                        const u32 sad = __builtin_amdgcn_sad_u8(p[j], ctr[a][o], 0u);
-                        const u32 addr = __builtin_amdgcn_alignbit(sad, lane_hi, 25);
-                        const float wgt = spw * *(const float*)((const u8*)cw + addr);
+                        // word index class * 768 + |db| + |dg| + |dr| in one v_sad_u8 (the class offset is its accumulator)
+                        const u32 idx = __builtin_amdgcn_sad_u8(p[j], ctr[a][o], (u32)toff);
+                        const float wgt = *(const float*)((const u8*)fw + (idx << 2));
                         // v_muladd(v_cvt_f32(b), w, sum_b): fused, like OpenCV's FMA3-dispatched body
                         sb[a][o] = __fmaf_rn(fb[j], wgt, sb[a][o]);
                         sg[a][o] = __fmaf_rn(fg[j], wgt, sg[a][o]);
