@@ -190,6 +190,7 @@ def load():
         "cbv_noise_run": (i32, [vp, vp, i32, P(NoiseDevState), P(NoiseResult)]),
         "cbv_pipeline_host_ring": (C.c_void_p, [vp]),
         "cbv_pipeline_submit": (i32, [vp, i32, i32]),
+        "cbv_pipeline_wait_submitted": (i32, [vp]),
         "cbv_pipeline_update_references": (i32, [vp, i32, i32]),
         "cbv_pipeline_set_check_squares": (i32, [vp, i32, i32, vp]),
         "cbv_pipeline_square_stats": (i32, [vp, i32, P(SqStats)]),

@@ -330,7 +330,7 @@ extern "C" int cbv_apply_color_profile(cbv_ctx* ctx, const uint8_t* bgr, int w, 
 {
     RC(check_img(ctx, bgr, w, h, stride, 3, "cbv_apply_color_profile"));
     if (!out || !profile) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_apply_color_profile: null argument");
-    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_ENTER(ctx);
     RC(upload(ctx, &ctx->in, bgr, w * 3, h, stride));
     if (!profile->enabled) return download(ctx, ctx->in.p, out, w * 3, h, out_stride); // `{}` profile: identity
     RC(ctx_set_profile(ctx, profile));
@@ -348,7 +348,7 @@ extern "C" int cbv_correct_lighting(cbv_ctx* ctx, const uint8_t* bgr, int w, int
 {
     RC(check_img(ctx, bgr, w, h, stride, 3, "cbv_correct_lighting"));
     if (!out || tiles_x <= 0 || tiles_y <= 0 || tiles_x > 64 || tiles_y > 64) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_correct_lighting: bad arguments");
-    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_ENTER(ctx);
     RC(upload(ctx, &ctx->in, bgr, w * 3, h, stride));
     Geom g = tight_geom(w, h);
     RC(dev_ensure(ctx, &ctx->a, g.frame_stride));
@@ -369,7 +369,7 @@ extern "C" int cbv_reduce_noise(cbv_ctx* ctx, const uint8_t* bgr, int w, int h, 
 {
     RC(check_img(ctx, bgr, w, h, stride, 3, "cbv_reduce_noise"));
     if (!out) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_reduce_noise: out is null");
-    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_ENTER(ctx);
     RC(ctx_set_bilateral(ctx, d, sigma_color, sigma_space));
     RC(upload(ctx, &ctx->in, bgr, w * 3, h, stride));
     Geom g = tight_geom(w, h);
@@ -383,7 +383,7 @@ extern "C" int cbv_sharpen(cbv_ctx* ctx, const uint8_t* bgr, int w, int h, int s
 {
     RC(check_img(ctx, bgr, w, h, stride, 3, "cbv_sharpen"));
     if (!out || !kernel9) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_sharpen: null argument");
-    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_ENTER(ctx);
     RC(upload(ctx, &ctx->in, bgr, w * 3, h, stride));
     Geom g = tight_geom(w, h);
     RC(dev_ensure(ctx, &ctx->a, g.frame_stride));
@@ -401,7 +401,7 @@ extern "C" int cbv_normalize_intensity(cbv_ctx* ctx, const uint8_t* bgr, int w, 
 {
     RC(check_img(ctx, bgr, w, h, stride, 3, "cbv_normalize_intensity"));
     if (!out) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_normalize_intensity: out is null");
-    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_ENTER(ctx);
     RC(upload(ctx, &ctx->in, bgr, w * 3, h, stride));
     Geom g = tight_geom(w, h);
     RC(dev_ensure(ctx, &ctx->a, g.frame_stride));
@@ -419,7 +419,7 @@ extern "C" int cbv_prepare_analysis(cbv_ctx* ctx, const uint8_t* bgr, int w, int
 {
     RC(check_img(ctx, bgr, w, h, stride, 3, "cbv_prepare_analysis"));
     if (!gray || !binary) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_prepare_analysis: null output");
-    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_ENTER(ctx);
     RC(upload(ctx, &ctx->in, bgr, w * 3, h, stride));
     Geom g = tight_geom(w, h);
     size_t plane = ((size_t)w * h + 255) & ~(size_t)255;
@@ -447,7 +447,7 @@ extern "C" int cbv_canny(cbv_ctx* ctx, const uint8_t* img, int w, int h, int str
 {
     RC(check_img(ctx, img, w, h, stride, cn, "cbv_canny"));
     if (!edges || (cn != 1 && cn != 3)) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_canny: null output or unsupported channel count");
-    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_ENTER(ctx);
     RC(upload(ctx, &ctx->in, img, w * cn, h, stride));
     // cv::Canny: thresholds are ordered, then floored (L1 gradient)
     double lo = threshold1 < threshold2 ? threshold1 : threshold2, hi = threshold1 < threshold2 ? threshold2 : threshold1;
@@ -482,7 +482,7 @@ extern "C" int cbv_find_chessboard_corners(cbv_ctx* ctx, const uint8_t* bgr, int
 {
     RC(check_img(ctx, bgr, w, h, stride, 3, "cbv_find_chessboard_corners"));
     if (!pts8) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_find_chessboard_corners: null output");
-    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_ENTER(ctx);
     RC(upload(ctx, &ctx->in, bgr, w * 3, h, stride));
     const size_t plane = ((size_t)w * h + 255) & ~(size_t)255;
     RC(dev_ensure(ctx, &ctx->a, plane * 3 + 256));
@@ -542,7 +542,7 @@ extern "C" int cbv_process_pipeline(cbv_ctx* ctx, const uint8_t* bgr, int w, int
 {
     RC(check_img(ctx, bgr, w, h, stride, 3, "cbv_process_pipeline"));
     if (!out) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_process_pipeline: out is null");
-    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_ENTER(ctx);
     RC(check_params(ctx, params));
     RC(upload(ctx, &ctx->in, bgr, w * 3, h, stride));
     Geom g = tight_geom(w, h);
@@ -560,7 +560,7 @@ extern "C" int cbv_warp_perspective(cbv_ctx* ctx, const uint8_t* bgr, int w, int
 {
     RC(check_img(ctx, bgr, w, h, stride, 3, "cbv_warp_perspective"));
     if (!out || !M9 || dw <= 0 || dh <= 0 || dw > 8192 || dh > 8192) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_warp_perspective: bad arguments");
-    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_ENTER(ctx);
     double Minv[9];
     if (!host_invert3x3(M9, Minv)) memset(Minv, 0, sizeof(Minv)); // cv::invert returns a zero matrix when singular
     RC(upload(ctx, &ctx->in, bgr, w * 3, h, stride));
@@ -579,7 +579,7 @@ struct cbv_squares {
     int blur_k = 0;
     std::vector<SquareDesc> descs;
     size_t plane_total = 0, mask_total = 0;
-    DevBuf d_descs, d_masks, d_gray, d_ref, d_mean, d_var, d_stats, d_select, d_coef, d_stage, d_hough;
+    DevBuf d_descs, d_masks, d_gray, d_ref, d_mean, d_var, d_stats, d_select, d_coef, d_stage, d_hough, d_retry;
     std::vector<u8> stage;
     bool has_ref = false, has_model = false;
     int coef_k = -1;
@@ -599,7 +599,7 @@ extern "C" void cbv_squares_destroy(cbv_squares* s)
     if (!s) return;
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
-    DevBuf* bufs[] = {&s->d_descs, &s->d_masks, &s->d_gray, &s->d_ref, &s->d_mean, &s->d_var, &s->d_stats, &s->d_select, &s->d_coef, &s->d_stage, &s->d_hough};
+    DevBuf* bufs[] = {&s->d_descs, &s->d_masks, &s->d_gray, &s->d_ref, &s->d_mean, &s->d_var, &s->d_stats, &s->d_select, &s->d_coef, &s->d_stage, &s->d_hough, &s->d_retry};
     for (auto b : bufs) dev_free(b);
     delete s;
 }
@@ -629,11 +629,12 @@ static int squares_set_geometry(cbv_squares* s, const int* ws, const int* hs, in
     bool same = (n == s->n);
     for (int i = 0; same && i < n; i++) same = s->descs[i].w == ws[i] && s->descs[i].h == hs[i];
     if (same) return CBV_OK;
+    for (int i = 0; i < n; i++) // validate before any state changes: a rejected load leaves the set as it was
+        if (ws[i] <= 0 || hs[i] <= 0 || ws[i] > CBV_MAX_SQUARE_DIM || hs[i] > CBV_MAX_SQUARE_DIM)
+            return cbv_fail(ctx, CBV_ERR_UNSUPPORTED, "square %d is %dx%d; supported up to %dx%d", i, ws[i], hs[i], CBV_MAX_SQUARE_DIM, CBV_MAX_SQUARE_DIM);
     s->descs.assign(n, SquareDesc());
     size_t off = 0;
     for (int i = 0; i < n; i++) {
-        if (ws[i] <= 0 || hs[i] <= 0 || ws[i] > CBV_MAX_SQUARE_DIM || hs[i] > CBV_MAX_SQUARE_DIM)
-            return cbv_fail(ctx, CBV_ERR_UNSUPPORTED, "square %d is %dx%d; supported up to %dx%d", i, ws[i], hs[i], CBV_MAX_SQUARE_DIM, CBV_MAX_SQUARE_DIM);
         s->descs[i].w = ws[i];
         s->descs[i].h = hs[i];
         s->descs[i].plane_off = (int)off;
@@ -662,7 +663,7 @@ extern "C" int cbv_squares_load(cbv_squares* s, const cbv_square_view* views, in
     if (!s) return CBV_ERR_ARG;
     cbv_ctx* ctx = s->ctx;
     if (!views || n <= 0 || n > CBV_MAX_SQUARES) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_squares_load: bad arguments (n=%d)", n);
-    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_ENTER(ctx);
     int ws[CBV_MAX_SQUARES], hs[CBV_MAX_SQUARES];
     for (int i = 0; i < n; i++) {
         if (!views[i].data) { // keep the current gray of this square (its geometry must already be known)
@@ -714,7 +715,7 @@ extern "C" int cbv_squares_load_dev(cbv_squares* s, const void* dev_img, int w, 
     if (!s) return CBV_ERR_ARG;
     cbv_ctx* ctx = s->ctx;
     if (!dev_img || !rois || n <= 0 || n > CBV_MAX_SQUARES || (cn != 1 && cn != 3)) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_squares_load_dev: bad arguments");
-    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_ENTER(ctx);
     int ws[CBV_MAX_SQUARES], hs[CBV_MAX_SQUARES];
     for (int i = 0; i < n; i++) {
         if (rois[i].x0 < 0 || rois[i].y0 < 0 || rois[i].x0 + rois[i].w > w || rois[i].y0 + rois[i].h > h)
@@ -753,7 +754,7 @@ extern "C" int cbv_squares_calibrate(cbv_squares* s, double initial_variance, co
     if (!s) return CBV_ERR_ARG;
     cbv_ctx* ctx = s->ctx;
     if (s->n == 0) return cbv_fail(ctx, CBV_ERR_STATE, "cbv_squares_calibrate: no squares loaded");
-    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_ENTER(ctx);
     const u8* sel;
     RC(squares_select(s, select, &sel));
     RC(launch_squares_calibrate(ctx, (const SquareDesc*)s->d_descs.p, s->n, (const u8*)s->d_gray.p, (float*)s->d_mean.p, (float*)s->d_var.p,
@@ -768,7 +769,7 @@ extern "C" int cbv_squares_ema(cbv_squares* s, double alpha, const uint8_t* sele
     if (!s) return CBV_ERR_ARG;
     cbv_ctx* ctx = s->ctx;
     if (!s->has_model) return cbv_fail(ctx, CBV_ERR_STATE, "cbv_squares_ema: not calibrated");
-    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_ENTER(ctx);
     const u8* sel;
     RC(squares_select(s, select, &sel));
     RC(launch_squares_ema(ctx, (const SquareDesc*)s->d_descs.p, s->n, (const u8*)s->d_gray.p, (float*)s->d_mean.p, (float*)s->d_var.p, alpha, sel));
@@ -781,7 +782,7 @@ extern "C" int cbv_squares_set_ref(cbv_squares* s, const uint8_t* select)
     if (!s) return CBV_ERR_ARG;
     cbv_ctx* ctx = s->ctx;
     if (s->n == 0) return cbv_fail(ctx, CBV_ERR_STATE, "cbv_squares_set_ref: no squares loaded");
-    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_ENTER(ctx);
     const u8* sel;
     RC(squares_select(s, select, &sel));
     RC(launch_squares_set_ref(ctx, (const SquareDesc*)s->d_descs.p, s->n, (const u8*)s->d_gray.p, (u8*)s->d_ref.p, sel));
@@ -796,7 +797,7 @@ extern "C" int cbv_squares_stats(cbv_squares* s, int use_ref, int use_model, dou
     cbv_ctx* ctx = s->ctx;
     if (!out || s->n == 0) return cbv_fail(ctx, CBV_ERR_STATE, "cbv_squares_stats: no squares loaded or null output");
     if (use_model && !s->has_model) return cbv_fail(ctx, CBV_ERR_STATE, "cbv_squares_stats: model requested but not calibrated");
-    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_ENTER(ctx);
     RC(launch_squares_stats(ctx, (const SquareDesc*)s->d_descs.p, s->n, (const u8*)s->d_gray.p, 0, use_ref ? (const u8*)s->d_ref.p : nullptr,
                             use_model ? (const float*)s->d_mean.p : nullptr, use_model ? (const float*)s->d_var.p : nullptr,
                             (const u8*)s->d_masks.p, (float)z_threshold, (cbv_sq_stats*)s->d_stats.p, 1));
@@ -830,11 +831,13 @@ extern "C" int cbv_squares_hough(cbv_squares* s, const cbv_hough_params* prm, cb
     if (!s) return CBV_ERR_ARG;
     cbv_ctx* ctx = s->ctx;
     if (!out || s->n == 0) return cbv_fail(ctx, CBV_ERR_STATE, "cbv_squares_hough: no squares loaded or null output");
-    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_ENTER(ctx);
     HoughCfg hc;
     RC(hough_cfg(ctx, prm, s->descs, &hc));
     RC(dev_ensure(ctx, &s->d_hough, sizeof(cbv_hough_result) * CBV_MAX_SQUARES));
-    RC(launch_hough(ctx, (const SquareDesc*)s->d_descs.p, s->n, (const u8*)s->d_gray.p, 0, hc, (cbv_hough_result*)s->d_hough.p, nullptr, nullptr, 1));
+    RC(dev_ensure(ctx, &s->d_retry, sizeof(u32) * (1 + CBV_MAX_SQUARES)));
+    RC(launch_hough(ctx, (const SquareDesc*)s->d_descs.p, s->n, (const u8*)s->d_gray.p, 0, hc, (cbv_hough_result*)s->d_hough.p, nullptr, nullptr, 1,
+                    (u32*)s->d_retry.p));
     CBV_HIP(ctx, hipMemcpyAsync(out, s->d_hough.p, sizeof(cbv_hough_result) * s->n, hipMemcpyDeviceToHost, ctx->stream));
     CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return CBV_OK;
@@ -863,7 +866,7 @@ extern "C" int cbv_squares_get(cbv_squares* s, int which, int index, void* out)
     void* p;
     size_t bytes;
     RC(squares_plane(s, which, index, &p, &bytes));
-    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_ENTER(ctx);
     CBV_HIP(ctx, hipMemcpyAsync(out, p, bytes, hipMemcpyDeviceToHost, ctx->stream));
     CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return CBV_OK;
@@ -876,7 +879,7 @@ extern "C" int cbv_squares_set(cbv_squares* s, int which, int index, const void*
     void* p;
     size_t bytes;
     RC(squares_plane(s, which, index, &p, &bytes));
-    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_ENTER(ctx);
     CBV_HIP(ctx, hipMemcpyAsync(p, in, bytes, hipMemcpyHostToDevice, ctx->stream));
     CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (which == 1) s->has_ref = true;
@@ -913,11 +916,12 @@ struct cbv_pipeline {
     u8* A[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
     u8* B[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
     DevBuf lane_small[MAX_LANES];
+    DevBuf lane_retry[MAX_LANES]; // HoughCircles second-pass list of the lane's current chunk (HoughCfg::retry)
     DevBuf lane_work[MAX_LANES]; // HoughCircles worklist of the lane's current chunk: count, then frame << 8 | square
     u8* enhanced = nullptr; // [max_frames] when keep_enhanced
     u8* warped = nullptr;   // [max_frames][S][S][3]
     size_t warped_stride = 0;
-    DevBuf d_descs, d_masks, d_gray, d_stats, d_ref, d_state, d_results, d_flags, d_dec, d_coef, d_synth, d_mean, d_var, d_noise, d_noise_state, d_hough, d_check;
+    DevBuf d_descs, d_masks, d_gray, d_stats, d_ref, d_state, d_results, d_flags, d_dec, d_coef, d_synth, d_mean, d_var, d_noise, d_noise_state, d_hough, d_check, d_hough_over;
     bool has_check = false; // squares_to_check masks were set
     HoughCfg hough_cfg;
     bool calibrated = false;
@@ -932,25 +936,72 @@ struct cbv_pipeline {
         bool pending;
     };
     std::vector<CopyRec> copies;
-    hipEvent_t run_done = nullptr;
-    int last_run_s0 = 0, last_run_cnt = 0;
     // The temporal scan (+ NoiseHandler) of a run goes to its own stream behind the lanes' events, so the next run's
     // enhancement of OTHER slots overlaps it; scans of successive runs stay ordered on that stream.
     hipStream_t scan_stream = nullptr;
-    hipEvent_t scan_done = nullptr, main_done = nullptr;
-    bool scan_pending = false;
-    int scan_s0 = 0, scan_cnt = 0;
+    hipEvent_t main_done = nullptr;
+    // Every run that may still be executing: its slot range and two events on the (in-order) scan stream,
+    // `lanes_ev` = all lanes have read the input frames and written the per-slot buffers, `scan_ev` = the scan has
+    // read them.  A later run (or ingest copy) that touches overlapping slots waits on the NEWEST overlapping
+    // record, which covers the older ones because the scan stream is in order.  Records are recycled once their
+    // scan event has completed.
+    struct RunRec {
+        int s0, cnt;
+        unsigned long long seq;
+        hipEvent_t lanes_ev, scan_ev;
+        bool live;
+    };
+    std::vector<RunRec> runs;
+    unsigned long long run_seq = 0;         // sequence number of the newest run
+    unsigned long long joined_seq = 0;      // runs up to this one are ordered before later work on `joined_stream`
+    hipStream_t joined_stream = nullptr;
     int max_px = 0; // pixels of the largest square
     bool keep_enhanced = false;
 };
 
-// make the context's stream wait for everything the last run enqueued (lanes and scan)
+static bool ranges_overlap(int a0, int an, int b0, int bn) { return a0 < b0 + bn && b0 < a0 + an; }
+
+static void retire_runs(cbv_pipeline* p)
+{
+    for (auto& r : p->runs)
+        if (r.live && hipEventQuery(r.scan_ev) == hipSuccess) r.live = false;
+}
+
+// newest record that is still in flight, not yet ordered before the context's stream, and overlaps the slots
+// (cnt <= 0: any slots)
+static cbv_pipeline::RunRec* newest_unjoined(cbv_pipeline* p, int s0, int cnt)
+{
+    if (p->joined_stream != p->ctx->stream) { // the caller switched streams: nothing is ordered before the new one
+        p->joined_stream = p->ctx->stream;
+        p->joined_seq = 0;
+    }
+    cbv_pipeline::RunRec* best = nullptr;
+    for (auto& r : p->runs)
+        if (r.live && r.seq > p->joined_seq && (cnt <= 0 || ranges_overlap(s0, cnt, r.s0, r.cnt)) && (!best || r.seq > best->seq)) best = &r;
+    return best;
+}
+
+// make the context's stream wait for every run that is still in flight (lanes and scans)
 static int join_scan(cbv_pipeline* p)
 {
     cbv_ctx* ctx = p->ctx;
-    if (p->scan_pending) {
-        CBV_HIP(ctx, hipStreamWaitEvent(ctx->stream, p->scan_done, 0));
-        p->scan_pending = false;
+    if (cbv_pipeline::RunRec* r = newest_unjoined(p, 0, 0)) {
+        CBV_HIP(ctx, hipStreamWaitEvent(ctx->stream, r->scan_ev, 0));
+        p->joined_seq = r->seq;
+    }
+    return CBV_OK;
+}
+
+// make the context's stream wait for the runs in flight that touch these slots (older scans of the same slots
+// may still be queued: the newest overlapping record covers them)
+static int join_slots(cbv_pipeline* p, int s0, int cnt)
+{
+    cbv_ctx* ctx = p->ctx;
+    retire_runs(p);
+    if (cbv_pipeline::RunRec* r = newest_unjoined(p, s0, cnt)) {
+        CBV_HIP(ctx, hipStreamWaitEvent(ctx->stream, r->scan_ev, 0));
+        // everything up to r is ordered now; records between joined_seq and r.seq that do not overlap are too
+        p->joined_seq = std::max(p->joined_seq, r->seq);
     }
     return CBV_OK;
 }
@@ -958,7 +1009,7 @@ static int join_scan(cbv_pipeline* p)
 extern "C" int cbv_pipeline_create(cbv_ctx* ctx, int w, int h, int max_frames, cbv_pipeline** out)
 {
     if (!ctx || !out || w <= 0 || h <= 0 || max_frames <= 0) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_pipeline_create: bad arguments");
-    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_ENTER(ctx);
     cbv_pipeline* p = new cbv_pipeline();
     p->ctx = ctx;
     p->w = w;
@@ -985,6 +1036,7 @@ extern "C" void cbv_pipeline_destroy(cbv_pipeline* p)
         if (p->B[l]) (void)hipFree(p->B[l]);
         dev_free(&p->lane_small[l]);
         dev_free(&p->lane_work[l]);
+        dev_free(&p->lane_retry[l]);
         if (p->lane_done[l]) (void)hipEventDestroy(p->lane_done[l]);
         if (p->lane_stream[l]) (void)hipStreamDestroy(p->lane_stream[l]);
     }
@@ -993,19 +1045,21 @@ extern "C" void cbv_pipeline_destroy(cbv_pipeline* p)
         (void)hipStreamSynchronize(p->scan_stream);
         (void)hipStreamDestroy(p->scan_stream);
     }
-    if (p->scan_done) (void)hipEventDestroy(p->scan_done);
+    for (auto& r : p->runs) {
+        (void)hipEventDestroy(r.lanes_ev);
+        (void)hipEventDestroy(r.scan_ev);
+    }
     if (p->main_done) (void)hipEventDestroy(p->main_done);
     if (p->copy_stream) {
         (void)hipStreamSynchronize(p->copy_stream);
         (void)hipStreamDestroy(p->copy_stream);
     }
     for (auto& c : p->copies) (void)hipEventDestroy(c.ev);
-    if (p->run_done) (void)hipEventDestroy(p->run_done);
     if (p->host_ring) (void)hipHostFree(p->host_ring);
     if (p->frames) (void)hipFree(p->frames);
     if (p->enhanced) (void)hipFree(p->enhanced);
     if (p->warped) (void)hipFree(p->warped);
-    DevBuf* bufs[] = {&p->d_descs, &p->d_masks, &p->d_gray, &p->d_stats, &p->d_ref, &p->d_state, &p->d_results, &p->d_flags, &p->d_dec, &p->d_noise, &p->d_noise_state, &p->d_coef, &p->d_synth, &p->d_mean, &p->d_var, &p->d_hough, &p->d_check};
+    DevBuf* bufs[] = {&p->d_descs, &p->d_masks, &p->d_gray, &p->d_stats, &p->d_ref, &p->d_state, &p->d_results, &p->d_flags, &p->d_dec, &p->d_noise, &p->d_noise_state, &p->d_coef, &p->d_synth, &p->d_mean, &p->d_var, &p->d_hough, &p->d_check, &p->d_hough_over};
     for (auto b : bufs) dev_free(b);
     delete p;
 }
@@ -1016,12 +1070,21 @@ extern "C" int cbv_pipeline_configure(cbv_pipeline* p, const cbv_pipeline_config
 {
     if (!p || !cfg) return CBV_ERR_ARG;
     cbv_ctx* ctx = p->ctx;
-    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_ENTER(ctx);
     RC(join_scan(p)); // lanes and scan of the last run
     if (cfg->n_rois <= 0 || cfg->n_rois > CBV_MAX_SQUARES || cfg->board_size <= 0 || cfg->board_size > 4096)
         return cbv_fail(ctx, CBV_ERR_ARG, "cbv_pipeline_configure: bad board/roi configuration");
     if (cfg->history_size < 1 || cfg->history_size > 7) return cbv_fail(ctx, CBV_ERR_ARG, "history_size must be in 1..7");
     RC(check_params(ctx, &cfg->enhance));
+    for (int i = 0; i < cfg->n_rois; i++) {
+        const cbv_roi& r = cfg->rois[i];
+        if (r.w <= 0 || r.h <= 0 || r.w > CBV_MAX_SQUARE_DIM || r.h > CBV_MAX_SQUARE_DIM || r.x0 < 0 || r.y0 < 0 ||
+            r.x0 + r.w > cfg->board_size || r.y0 + r.h > cfg->board_size)
+            return cbv_fail(ctx, CBV_ERR_ARG, "roi %d is invalid for a %dx%d board", i, cfg->board_size, cfg->board_size);
+    }
+    // every argument check that needs no state is done; from here on a failure leaves the pipeline UNconfigured
+    // (run / results / ... return CBV_ERR_STATE) instead of half reconfigured
+    p->configured = false;
     CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     p->cfg = *cfg;
     p->keep_enhanced = cfg->keep_enhanced != 0;
@@ -1052,6 +1115,7 @@ extern "C" int cbv_pipeline_configure(cbv_pipeline* p, const cbv_pipeline_config
         SmallLayout SL;
         RC(small_layout(ctx, &p->lane_small[l], cfg->enhance.tiles_x * cfg->enhance.tiles_y, chunk, &SL));
         RC(dev_ensure(ctx, &p->lane_work[l], sizeof(u32) * (1 + (size_t)CBV_MAX_SQUARES * chunk)));
+        RC(dev_ensure(ctx, &p->lane_retry[l], sizeof(u32) * (1 + (size_t)CBV_MAX_SQUARES * chunk)));
         if (l > 0 && !p->lane_stream[l]) CBV_HIP(ctx, hipStreamCreateWithFlags(&p->lane_stream[l], hipStreamNonBlocking));
         if (!p->lane_done[l]) CBV_HIP(ctx, hipEventCreateWithFlags(&p->lane_done[l], hipEventDisableTiming));
     }
@@ -1063,8 +1127,6 @@ extern "C" int cbv_pipeline_configure(cbv_pipeline* p, const cbv_pipeline_config
     size_t off = 0;
     for (int i = 0; i < n; i++) {
         const cbv_roi& r = cfg->rois[i];
-        if (r.w <= 0 || r.h <= 0 || r.w > CBV_MAX_SQUARE_DIM || r.h > CBV_MAX_SQUARE_DIM || r.x0 < 0 || r.y0 < 0 || r.x0 + r.w > S || r.y0 + r.h > S)
-            return cbv_fail(ctx, CBV_ERR_ARG, "roi %d is invalid for a %dx%d board", i, S, S);
         SquareDesc& d = p->descs[i];
         d.w = r.w;
         d.h = r.h;
@@ -1095,6 +1157,9 @@ extern "C" int cbv_pipeline_configure(cbv_pipeline* p, const cbv_pipeline_config
     if (cfg->use_hough) {
         RC(hough_cfg(ctx, &cfg->hough, p->descs, &p->hough_cfg));
         RC(dev_ensure(ctx, &p->d_hough, sizeof(cbv_hough_result) * CBV_MAX_SQUARES * p->max_frames));
+        RC(dev_ensure(ctx, &p->d_hough_over, 256));
+        CBV_HIP(ctx, hipMemset(p->d_hough_over.p, 0, 256));
+        p->hough_cfg.overflow_count = (u32*)p->d_hough_over.p;
     }
     RC(dev_ensure(ctx, &p->d_noise, sizeof(cbv_noise_result) * p->max_frames));
     RC(dev_ensure(ctx, &p->d_noise_state, sizeof(cbv_noise_state)));
@@ -1120,10 +1185,11 @@ extern "C" int cbv_pipeline_reset_state(cbv_pipeline* p)
 {
     if (!p || !p->configured) return CBV_ERR_STATE;
     cbv_ctx* ctx = p->ctx;
-    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_ENTER(ctx);
     RC(join_scan(p)); // lanes and scan of the last run
     CBV_HIP(ctx, hipMemsetAsync(p->d_state.p, 0, sizeof(ScanState) * p->cfg.n_rois, ctx->stream));
     CBV_HIP(ctx, hipMemsetAsync(p->d_noise_state.p, 0, sizeof(cbv_noise_state), ctx->stream));
+    if (p->d_hough_over.p) CBV_HIP(ctx, hipMemsetAsync(p->d_hough_over.p, 0, 4, ctx->stream));
     return CBV_OK;
 }
 
@@ -1132,7 +1198,7 @@ extern "C" int cbv_pipeline_calibrate(cbv_pipeline* p, int slot)
     if (!p || !p->configured) return CBV_ERR_STATE;
     cbv_ctx* ctx = p->ctx;
     if (slot < 0 || slot >= p->max_frames) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_pipeline_calibrate: bad slot");
-    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_ENTER(ctx);
     RC(join_scan(p)); // lanes and scan of the last run
     RC(launch_squares_calibrate(ctx, (const SquareDesc*)p->d_descs.p, p->cfg.n_rois, (const u8*)p->d_gray.p + p->plane_total * slot,
                                 (float*)p->d_mean.p, (float*)p->d_var.p, (float)p->cfg.initial_variance, nullptr));
@@ -1145,7 +1211,7 @@ extern "C" int cbv_pipeline_update_references(cbv_pipeline* p, int slot, int res
     if (!p || !p->configured) return CBV_ERR_STATE;
     cbv_ctx* ctx = p->ctx;
     if (slot < 0 || slot >= p->max_frames) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_pipeline_update_references: bad slot");
-    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_ENTER(ctx);
     RC(join_scan(p)); // lanes and scan of the last run
     RC(launch_scan_update_refs(ctx, (const SquareDesc*)p->d_descs.p, p->cfg.n_rois, (const u8*)p->d_gray.p + p->plane_total * slot,
                                (u8*)p->d_ref.p, (ScanState*)p->d_state.p));
@@ -1157,7 +1223,7 @@ extern "C" int cbv_pipeline_upload(cbv_pipeline* p, int slot, const uint8_t* bgr
 {
     if (!p || !bgr || slot < 0 || slot >= p->max_frames || stride < p->w * 3) return CBV_ERR_ARG;
     cbv_ctx* ctx = p->ctx;
-    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_ENTER(ctx);
     RC(join_scan(p)); // lanes and scan of the last run
     CBV_HIP(ctx, hipMemcpy2DAsync(p->frames + p->g.frame_stride * slot, p->w * 3, bgr, stride, p->w * 3, p->h, hipMemcpyHostToDevice, ctx->stream));
     CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1178,19 +1244,22 @@ extern "C" uint8_t* cbv_pipeline_host_ring(cbv_pipeline* p)
     return p->host_ring;
 }
 
-static bool ranges_overlap(int a0, int an, int b0, int bn) { return a0 < b0 + bn && b0 < a0 + an; }
-
 extern "C" int cbv_pipeline_submit(cbv_pipeline* p, int slot0, int count)
 {
     if (!p) return CBV_ERR_ARG;
     cbv_ctx* ctx = p->ctx;
     if (slot0 < 0 || count <= 0 || slot0 + count > p->max_frames) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_pipeline_submit: bad slot range");
     if (!p->host_ring) return cbv_fail(ctx, CBV_ERR_STATE, "cbv_pipeline_submit: cbv_pipeline_host_ring() was never called");
-    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_ENTER(ctx);
     if (!p->copy_stream) CBV_HIP(ctx, hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
-    // do not overwrite device slots a run that is still in flight reads
-    if (p->run_done && ranges_overlap(slot0, count, p->last_run_s0, p->last_run_cnt))
-        CBV_HIP(ctx, hipStreamWaitEvent(p->copy_stream, p->run_done, 0));
+    // do not overwrite device slots a run that is still in flight reads: ANY such run, not only the last one
+    retire_runs(p);
+    {
+        cbv_pipeline::RunRec* best = nullptr;
+        for (auto& r : p->runs)
+            if (r.live && ranges_overlap(slot0, count, r.s0, r.cnt) && (!best || r.seq > best->seq)) best = &r;
+        if (best) CBV_HIP(ctx, hipStreamWaitEvent(p->copy_stream, best->lanes_ev, 0));
+    }
     CBV_HIP(ctx, hipMemcpyAsync(p->frames + p->g.frame_stride * slot0, p->host_ring + p->g.frame_stride * slot0,
                                 p->g.frame_stride * count, hipMemcpyHostToDevice, p->copy_stream));
     cbv_pipeline::CopyRec* rec = nullptr;
@@ -1212,12 +1281,21 @@ extern "C" int cbv_pipeline_submit(cbv_pipeline* p, int slot0, int count)
     return CBV_OK;
 }
 
+extern "C" int cbv_pipeline_wait_submitted(cbv_pipeline* p)
+{
+    if (!p) return CBV_ERR_ARG;
+    cbv_ctx* ctx = p->ctx;
+    CBV_ENTER(ctx);
+    if (p->copy_stream) CBV_HIP(ctx, hipStreamSynchronize(p->copy_stream));
+    return CBV_OK;
+}
+
 extern "C" int cbv_pipeline_synth(cbv_pipeline* p, int slot0, int count, const uint64_t* seeds, const double* Hinv9,
                                   const uint8_t* boards, const cbv_scene* scene)
 {
     if (!p || !seeds || !Hinv9 || !boards || !scene || slot0 < 0 || count <= 0 || slot0 + count > p->max_frames) return CBV_ERR_ARG;
     cbv_ctx* ctx = p->ctx;
-    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_ENTER(ctx);
     RC(join_scan(p)); // lanes and scan of the last run
     size_t o_seeds = 0, o_h = (size_t)count * 8, o_b = o_h + 72, o_s = (o_b + (size_t)count * 64 + 15) & ~(size_t)15;
     size_t total = o_s + sizeof(cbv_scene);
@@ -1241,13 +1319,13 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
     if (!p || !p->configured) return CBV_ERR_STATE;
     cbv_ctx* ctx = p->ctx;
     if (slot0 < 0 || count <= 0 || slot0 + count > p->max_frames) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_pipeline_run: bad slot range");
-    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_ENTER(ctx);
     const cbv_pipeline_config& cfg = p->cfg;
     const int S = cfg.board_size, n = cfg.n_rois;
     // Lane 0 is the context's stream; lanes 1.. are worker streams forked from it and joined before
     // the temporal scan (which needs every frame's statistics, in order).
     hipStream_t main_stream = ctx->stream;
-    if (p->scan_pending && ranges_overlap(slot0, count, p->scan_s0, p->scan_cnt)) RC(join_scan(p)); // it still reads these slots' planes
+    RC(join_slots(p, slot0, count)); // scans in flight that still read these slots' planes, however many runs back
     for (auto& c : p->copies) // ingest copies of these slots must have landed
         if (c.pending && ranges_overlap(slot0, count, c.s0, c.cnt)) {
             CBV_HIP(ctx, hipStreamWaitEvent(main_stream, c.ev, 0));
@@ -1299,14 +1377,27 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
         if (rc_all) break;
         if (cfg.use_hough)
             rc_all = launch_hough(ctx, (const SquareDesc*)p->d_descs.p, n, (const u8*)p->d_gray.p + p->plane_total * s0, p->plane_total,
-                                  p->hough_cfg, hres, dec, work, b);
+                                  p->hough_cfg, hres, dec, work, b, (u32*)p->lane_retry[lane].p);
     }
     ctx->stream = main_stream;
     if (rc_all) return rc_all;
     if (!p->scan_stream) {
         CBV_HIP(ctx, hipStreamCreateWithFlags(&p->scan_stream, hipStreamNonBlocking));
-        CBV_HIP(ctx, hipEventCreateWithFlags(&p->scan_done, hipEventDisableTiming));
         CBV_HIP(ctx, hipEventCreateWithFlags(&p->main_done, hipEventDisableTiming));
+    }
+    retire_runs(p);
+    cbv_pipeline::RunRec* rec = nullptr;
+    for (auto& r : p->runs)
+        if (!r.live) {
+            rec = &r;
+            break;
+        }
+    if (!rec) {
+        cbv_pipeline::RunRec r{0, 0, 0, nullptr, nullptr, false};
+        CBV_HIP(ctx, hipEventCreateWithFlags(&r.lanes_ev, hipEventDisableTiming));
+        CBV_HIP(ctx, hipEventCreateWithFlags(&r.scan_ev, hipEventDisableTiming));
+        p->runs.push_back(r);
+        rec = &p->runs.back();
     }
     CBV_HIP(ctx, hipEventRecord(p->main_done, main_stream));
     CBV_HIP(ctx, hipStreamWaitEvent(p->scan_stream, p->main_done, 0));
@@ -1314,12 +1405,8 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
         CBV_HIP(ctx, hipEventRecord(p->lane_done[l], p->lane_stream[l]));
         CBV_HIP(ctx, hipStreamWaitEvent(p->scan_stream, p->lane_done[l], 0));
     }
-    if (p->host_ring) { // every lane has read its frames: a later cbv_pipeline_submit may overwrite these slots
-        if (!p->run_done) CBV_HIP(ctx, hipEventCreateWithFlags(&p->run_done, hipEventDisableTiming));
-        CBV_HIP(ctx, hipEventRecord(p->run_done, p->scan_stream));
-        p->last_run_s0 = slot0;
-        p->last_run_cnt = count;
-    }
+    // every lane has read its frames: a later cbv_pipeline_submit may overwrite these slots after this event
+    CBV_HIP(ctx, hipEventRecord(rec->lanes_ev, p->scan_stream));
     ctx->stream = p->scan_stream;
     struct Restore {
         cbv_ctx* c;
@@ -1345,10 +1432,11 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
     // NoiseHandler on the frames' visual_changes sets (game_session.py:165)
     RC(launch_noise(ctx, &((const cbv_frame_result*)p->d_results.p + slot0)->visual_changes, sizeof(cbv_frame_result) / 8, count,
                     (cbv_noise_state*)p->d_noise_state.p, (cbv_noise_result*)p->d_noise.p + slot0));
-    CBV_HIP(ctx, hipEventRecord(p->scan_done, p->scan_stream));
-    p->scan_pending = true;
-    p->scan_s0 = slot0;
-    p->scan_cnt = count;
+    CBV_HIP(ctx, hipEventRecord(rec->scan_ev, p->scan_stream));
+    rec->s0 = slot0;
+    rec->cnt = count;
+    rec->seq = ++p->run_seq;
+    rec->live = true;
     return CBV_OK;
 }
 
@@ -1356,7 +1444,7 @@ extern "C" int cbv_pipeline_set_check_squares(cbv_pipeline* p, int slot0, int co
 {
     if (!p || !p->configured || slot0 < 0 || count <= 0 || slot0 + count > p->max_frames) return CBV_ERR_ARG;
     cbv_ctx* ctx = p->ctx;
-    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_ENTER(ctx);
     RC(join_scan(p)); // the last run's scan may still read the masks
     if (roi_masks) {
         CBV_HIP(ctx, hipMemcpyAsync((u64*)p->d_check.p + slot0, roi_masks, sizeof(u64) * count, hipMemcpyHostToDevice, ctx->stream));
@@ -1370,10 +1458,16 @@ extern "C" int cbv_pipeline_results(cbv_pipeline* p, int slot0, int count, cbv_f
 {
     if (!p || !out || slot0 < 0 || count <= 0 || slot0 + count > p->max_frames) return CBV_ERR_ARG;
     cbv_ctx* ctx = p->ctx;
-    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_ENTER(ctx);
     RC(join_scan(p)); // lanes and scan of the last run
     CBV_HIP(ctx, hipMemcpyAsync(out, (cbv_frame_result*)p->d_results.p + slot0, sizeof(cbv_frame_result) * count, hipMemcpyDeviceToHost, ctx->stream));
+    u32 over = 0;
+    if (p->configured && p->cfg.use_hough && p->d_hough_over.p)
+        CBV_HIP(ctx, hipMemcpyAsync(&over, p->d_hough_over.p, 4, hipMemcpyDeviceToHost, ctx->stream));
     CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (over) // a truncated candidate list may change has_piece: never hand that over as if it were HoughCircles' answer
+        return cbv_fail(ctx, CBV_ERR_UNSUPPORTED, "HoughCircles: the candidate list overflowed (more than 512 accumulator maxima) on %u square(s) "
+                        "since the last reset_state; those occupancy bits are not HoughCircles' (inspect cbv_pipeline_hough flags)", over);
     return CBV_OK;
 }
 
@@ -1381,7 +1475,7 @@ extern "C" int cbv_pipeline_noise_results(cbv_pipeline* p, int slot0, int count,
 {
     if (!p || !out || !p->configured || slot0 < 0 || count <= 0 || slot0 + count > p->max_frames) return CBV_ERR_ARG;
     cbv_ctx* ctx = p->ctx;
-    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_ENTER(ctx);
     RC(join_scan(p)); // lanes and scan of the last run
     CBV_HIP(ctx, hipMemcpyAsync(out, (cbv_noise_result*)p->d_noise.p + slot0, sizeof(cbv_noise_result) * count, hipMemcpyDeviceToHost, ctx->stream));
     CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1391,7 +1485,7 @@ extern "C" int cbv_pipeline_noise_results(cbv_pipeline* p, int slot0, int count,
 extern "C" int cbv_noise_run(cbv_ctx* ctx, const uint64_t* changes, int n, cbv_noise_state* state, cbv_noise_result* out)
 {
     if (!ctx || !changes || !state || !out || n <= 0) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_noise_run: bad arguments");
-    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_ENTER(ctx);
     size_t b_in = ((size_t)n * 8 + 255) & ~(size_t)255, b_out = ((size_t)n * sizeof(cbv_noise_result) + 255) & ~(size_t)255;
     RC(dev_ensure(ctx, &ctx->c, b_in + b_out + 256));
     u8* base = (u8*)ctx->c.p;
@@ -1408,7 +1502,7 @@ extern "C" int cbv_pipeline_download(cbv_pipeline* p, int which, int slot, uint8
 {
     if (!p || !out || slot < 0 || slot >= p->max_frames) return CBV_ERR_ARG;
     cbv_ctx* ctx = p->ctx;
-    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_ENTER(ctx);
     RC(join_scan(p)); // lanes and scan of the last run
     const u8* src;
     size_t bytes;
@@ -1435,7 +1529,7 @@ extern "C" int cbv_pipeline_hough(cbv_pipeline* p, int slot, cbv_hough_result* o
     if (!p || !out || slot < 0 || slot >= p->max_frames) return CBV_ERR_ARG;
     cbv_ctx* ctx = p->ctx;
     if (!p->configured || !p->cfg.use_hough) return cbv_fail(ctx, CBV_ERR_STATE, "cbv_pipeline_hough: the HoughCircles stage is not configured");
-    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_ENTER(ctx);
     RC(join_scan(p)); // lanes and scan of the last run
     CBV_HIP(ctx, hipMemcpyAsync(out, (const cbv_hough_result*)p->d_hough.p + (size_t)CBV_MAX_SQUARES * slot,
                                 sizeof(cbv_hough_result) * CBV_MAX_SQUARES, hipMemcpyDeviceToHost, ctx->stream));
@@ -1447,7 +1541,7 @@ extern "C" int cbv_pipeline_square_stats(cbv_pipeline* p, int slot, cbv_sq_stats
 {
     if (!p || !out || !p->configured || slot < 0 || slot >= p->max_frames) return CBV_ERR_ARG;
     cbv_ctx* ctx = p->ctx;
-    CBV_HIP(ctx, hipSetDevice(ctx->device));
+    CBV_ENTER(ctx);
     RC(join_scan(p)); // lanes and scan of the last run
     CBV_HIP(ctx, hipMemcpyAsync(out, (cbv_sq_stats*)p->d_stats.p + (size_t)p->cfg.n_rois * slot, sizeof(cbv_sq_stats) * p->cfg.n_rois,
                                 hipMemcpyDeviceToHost, ctx->stream));

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -108,6 +109,11 @@ struct cbv_ctx {
     std::vector<hipEvent_t> prof_pool;
     double prof_ms[CBV_K_COUNT] = {0};
     long long prof_n[CBV_K_COUNT] = {0};
+
+    // One context = one queue of work: its scratch buffers and `stream` are shared by every object created on it, and
+    // cbv_pipeline_run points `stream` at its lanes while it enqueues.  Entry points that touch the GPU hold this lock
+    // for their whole call (CBV_ENTER), so calls from several threads on one context serialise instead of corrupting it.
+    std::recursive_mutex mu;
 };
 
 extern thread_local std::string g_cbv_err;
@@ -120,6 +126,11 @@ int cbv_fail(cbv_ctx* ctx, int code, const char* fmt, ...);
             return cbv_fail(ctx, CBV_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), \
                             __FILE__, __LINE__);                                                    \
     } while (0)
+
+// first statement of every entry point that uses the GPU through `ctx`
+#define CBV_ENTER(ctx)                                   \
+    std::lock_guard<std::recursive_mutex> lock__((ctx)->mu); \
+    CBV_HIP(ctx, hipSetDevice((ctx)->device))
 
 int dev_ensure(cbv_ctx* ctx, DevBuf* b, size_t bytes);
 void dev_free(DevBuf* b);
@@ -211,11 +222,16 @@ struct HoughCfg {
     int maxw, maxh; // largest square of the set
     int gs, mw, mag_bytes; // padded row strides of the gray/map planes (bytes) and the magnitude plane (u16)
     int off_map, off_mag, off_acc, off_centres, off_bins, off_order, max_bins;
+    u32* overflow_count; // device counter of squares whose candidate list overflowed (CBV_HOUGH_OVERFLOW), or null
+    int maxc;            // accumulator maxima / candidate circles kept per square (set by launch_hough)
+    u32* retry;          // first pass: squares with more than `maxc` maxima are listed here (count, then frame << 8 | square)
+                         // and done again by a second, rarely needed pass with room for every possible maximum
 };
 // `work` (may be null = every square of every frame): work[0] = number of items, work[1 + i] = frame << 8 | square,
 // as k_squares_stats lists them; a found circle sets bit 0 of the square's `decisions` byte.
+// `retry`: device scratch of 1 + n * batch words for the second pass (see HoughCfg::retry).
 int launch_hough(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, size_t gray_frame_stride, HoughCfg cfg,
-                 cbv_hough_result* out, u8* decisions, const u32* work, int batch);
+                 cbv_hough_result* out, u8* decisions, const u32* work, int batch, u32* retry);
 int launch_squares_pre5_stats(cbv_ctx* ctx, const u8* src, size_t src_frame_stride, const SquareDesc* descs, int n, u8* gray,
                               size_t gray_frame_stride, const float* mean, const float* var, const u8* masks, float z_thresh,
                               cbv_sq_stats* out, int batch, u8* decisions, int want_hough, u32* hough_work,

@@ -12,7 +12,8 @@
 // order in which edges or centres are visited, so the parallel order here is free.
 #include "cbv_device.h"
 
-#define HG_MAXC 512 // accumulator maxima / candidate circles kept per square
+#define HG_MAXC 512 // accumulator maxima / candidate circles the FIRST pass keeps per square; a square with more
+                    // (white noise, never a board square) is redone by the second pass, sized for the worst case
 #define HG_NT 1024  // lanes per workgroup: the phases are chains of LDS round trips, 16 waves hide them
 #define HG_NW (HG_NT / 64)
 
@@ -336,13 +337,21 @@ __global__ __launch_bounds__(HG_NT) void k_hough(const SquareDesc* __restrict__ 
         const int a = acc[base];
         if (a > cfg.acc_thr && a > acc[base - 1] && a >= acc[base + 1] && a > acc[base - astep] && a >= acc[base + astep]) {
             const int k = atomicAdd(&s_cnt[2], 1);
-            if (k < HG_MAXC) centres[k] = (u16)base;
+            if (k < cfg.maxc) centres[k] = (u16)base;
             else s_over = 1;
         }
     }
     __syncthreads();
     HG_TICK();
-    const int ncent = min(s_cnt[2], HG_MAXC);
+    if (s_over && cfg.retry) { // workgroup-uniform: hand the square to the second pass, decide nothing here
+        if (tid == 0) {
+            const u32 k = atomicAdd(&cfg.retry[0], 1u);
+            cfg.retry[1 + k] = ((u32)fri << 8) | (u32)sqi;
+        }
+        __syncthreads(); // s_over / s_cnt are reset at the top of the next item
+        continue;
+    }
+    const int ncent = min(s_cnt[2], cfg.maxc);
     // P6: radius of every centre.  Wave `wave` histograms centre c0 + wave into its own bins, turns them into
     // inclusive prefix sums plus "highest non-empty bin <= i"; then 16 lanes of wave 0 walk one centre each the way
     // the reference does: the highest non-empty bin opens a window of 10 bins, the walk resumes two bins below it.
@@ -522,6 +531,7 @@ __global__ __launch_bounds__(HG_NT) void k_hough(const SquareDesc* __restrict__ 
             r.n_edges = (uint32_t)nedges;
             r.n_centres = (uint16_t)ncent;
             r.flags = (uint16_t)(s_over ? CBV_HOUGH_OVERFLOW : 0);
+            if (s_over && cfg.overflow_count) atomicAdd(cfg.overflow_count, 1u);
             for (int i = 0; i < CBV_HOUGH_KEEP; i++) {
                 const bool ok = i < kept;
                 const HgCircle ci = ok ? circ[i] : HgCircle{0.f, 0.f, 0.f, 0};
@@ -568,25 +578,23 @@ static size_t hough_layout(HoughCfg& cfg)
     size_t off = 0;
     cfg.off_map = (int)up16(gbytes);
     off = cfg.off_map + up16(gbytes);
-    if (off < HG_MAXC * sizeof(HgCircle)) off = HG_MAXC * sizeof(HgCircle); // candidates overlay g + map
+    if (off < cfg.maxc * sizeof(HgCircle)) off = cfg.maxc * sizeof(HgCircle); // candidates overlay g + map
     cfg.off_mag = (int)off;
     off += (size_t)cfg.mag_bytes; // >= 2 bytes a pixel: the edge list reuses it
     cfg.off_acc = (int)off;
     off += up16(acells * 4 > maxn * 2 ? acells * 4 : maxn * 2); // the weak list (u16 a pixel) shares it
     cfg.off_centres = (int)off;
-    off += HG_MAXC * 2;
+    off += up16((size_t)cfg.maxc * 2);
     cfg.off_bins = (int)off;
     off += (size_t)HG_NW * cfg.max_bins * 4;
     cfg.off_order = (int)off; // candidates in HoughCircles' order
-    off += HG_MAXC * sizeof(HgCircle);
+    off += cfg.maxc * sizeof(HgCircle);
     return off;
 }
 
-int launch_hough(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, size_t gray_frame_stride, HoughCfg cfg,
-                 cbv_hough_result* out, u8* decisions, const u32* work, int batch)
+static int launch_hough_pass(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, size_t gray_frame_stride, HoughCfg cfg,
+                             cbv_hough_result* out, u8* decisions, const u32* work, int total, int max_grid)
 {
-    if (cfg.maxw < 2 || cfg.maxh < 2 || cfg.maxw > 250 || cfg.maxh > 250)
-        return cbv_fail(ctx, CBV_ERR_UNSUPPORTED, "HoughCircles stage: squares must be 2..250 px (got %dx%d)", cfg.maxw, cfg.maxh);
     const size_t lds = hough_layout(cfg);
     if (lds > 150 * 1024)
         return cbv_fail(ctx, CBV_ERR_UNSUPPORTED, "HoughCircles stage: %dx%d squares do not fit the LDS layout", cfg.maxw, cfg.maxh);
@@ -595,12 +603,44 @@ int launch_hough(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, s
     // as many workgroups as the chip holds at once (LDS-limited), striding over the work items
     const int per_cu = (int)(160 * 1024 / (lds + 1024)) < 2 ? ((int)(160 * 1024 / (lds + 1024)) < 1 ? 1 : (int)(160 * 1024 / (lds + 1024))) : 2;
     int grid = ctx->num_cus * per_cu;
-    const int total = n * batch;
+    if (grid > max_grid) grid = max_grid;
     if (grid > total) grid = total;
     if (grid < 1) grid = 1;
-    prof_begin(ctx, CBV_K_HOUGH);
     hipLaunchKernelGGL(k_hough, dim3(grid), dim3(HG_NT), lds, ctx->stream, descs, gray, gray_frame_stride, cfg, out, decisions, work, n, total);
-    prof_end(ctx, CBV_K_HOUGH);
     CBV_HIP(ctx, hipGetLastError());
+    return CBV_OK;
+}
+
+int launch_hough(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, size_t gray_frame_stride, HoughCfg cfg,
+                 cbv_hough_result* out, u8* decisions, const u32* work, int batch, u32* retry)
+{
+    if (cfg.maxw < 2 || cfg.maxh < 2 || cfg.maxw > 250 || cfg.maxh > 250)
+        return cbv_fail(ctx, CBV_ERR_UNSUPPORTED, "HoughCircles stage: squares must be 2..250 px (got %dx%d)", cfg.maxw, cfg.maxh);
+    const int total = n * batch;
+    prof_begin(ctx, CBV_K_HOUGH);
+    // first pass: small candidate lists (two workgroups per CU); squares that overflow them go to `retry`
+    cfg.maxc = HG_MAXC;
+    cfg.retry = retry;
+    if (retry) CBV_HIP(ctx, hipMemsetAsync(retry, 0, sizeof(u32), ctx->stream));
+    int rc = launch_hough_pass(ctx, descs, n, gray, gray_frame_stride, cfg, out, decisions, work, total, 1 << 30);
+    if (rc) return rc;
+    if (retry) {
+        // second pass over the listed squares only (normally none: the workgroups read a zero count and leave).
+        // No two 4-neighbours can both be maxima (a > left and a >= right exclude each other), so half the cells
+        // + 1 is room for every possible maximum; larger squares are capped by LDS and can still flag an overflow.
+        const float idp = 1.f / (cfg.dp < 1.f ? 1.f : cfg.dp);
+        const int cells = (int)ceilf(cfg.maxh * idp) * (int)ceilf(cfg.maxw * idp);
+        cfg.maxc = (cells + 1) / 2 + 1;
+        cfg.retry = nullptr;
+        for (;;) {
+            HoughCfg probe = cfg;
+            if (hough_layout(probe) <= 150 * 1024 || cfg.maxc <= HG_MAXC) break;
+            cfg.maxc = cfg.maxc * 3 / 4;
+        }
+        if (cfg.maxc < HG_MAXC) cfg.maxc = HG_MAXC;
+        rc = launch_hough_pass(ctx, descs, n, gray, gray_frame_stride, cfg, out, decisions, retry, total, 32);
+        if (rc) return rc;
+    }
+    prof_end(ctx, CBV_K_HOUGH);
     return CBV_OK;
 }

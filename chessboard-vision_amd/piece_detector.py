@@ -77,6 +77,10 @@ class PieceDetectorHIP:
         # np.std(gray) < 15  <=>  n*sumsq - sum^2 < 225 n^2
         if n * ss - s * s < 225 * n * n:
             return result
+        if hg is not None and hg.flags & N.HOUGH_OVERFLOW:
+            # more accumulator maxima than the kernel keeps: a truncated list could change has_piece, so it is
+            # never passed on as HoughCircles' answer
+            raise RuntimeError("HoughCircles candidate list overflowed (more than 512 accumulator maxima in a %dx%d square)" % (w, h))
         if hg is not None and hg.found:
             kind = "tower_top" if hg.kind == 2 else "hough"
             result.update(has_piece=True, center=(int(hg.cx), int(hg.cy)), radius=int(hg.r), method=kind,

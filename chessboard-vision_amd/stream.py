@@ -107,6 +107,10 @@ class BoardPipeline:
         """Enqueue host ring -> device ring for the slots; run() of those slots waits for the copy."""
         self.ctx.check(self.ctx.lib.cbv_pipeline_submit(self.h_, slot0, count))
 
+    def wait_submitted(self):
+        """Block until every submitted copy has left the host ring (runs stay in flight); the ring may be rewritten."""
+        self.ctx.check(self.ctx.lib.cbv_pipeline_wait_submitted(self.h_))
+
     def synth(self, slot0, count, stream_id=0, frame0=0, scene="normal", frames_per_ply=32, points=None):
         """Fill slots with synthetic frames of stream `stream_id`, frame indices
         frame0.. (scripted game, one ply every `frames_per_ply` frames)."""

@@ -320,10 +320,13 @@ CBV_API int cbv_pipeline_upload(cbv_pipeline* p, int slot, const uint8_t* bgr, i
 /* Ingest front end: a pinned host mirror of the frame ring ([max_frames][h][w][3], allocated on first call) that
  * the capture / decode side writes frames into, and an asynchronous copy of slots [slot0, slot0+count) to the
  * device ring on the pipeline's copy stream.  cbv_pipeline_run of those slots waits for their copy; a submit waits
- * for the last run when it would overwrite slots that run still reads.  Submitting batch k+1 before running batch k
+ * for every run still in flight that reads the slots it would overwrite (however many runs back).  Submitting batch k+1 before running batch k
  * overlaps PCIe with compute. */
 CBV_API uint8_t* cbv_pipeline_host_ring(cbv_pipeline* p);
 CBV_API int cbv_pipeline_submit(cbv_pipeline* p, int slot0, int count);
+/* Block until every submitted copy has left the pinned host ring (the copy stream only: runs stay in flight).
+ * After it returns the capture side may overwrite any host-ring slot again. */
+CBV_API int cbv_pipeline_wait_submitted(cbv_pipeline* p);
 /* fill slots with synthetic frames generated on the device */
 CBV_API int cbv_pipeline_synth(cbv_pipeline* p, int slot0, int count, const uint64_t* seeds, const double* Hinv9,
                        const uint8_t* boards /* count*64 */, const cbv_scene* scene);
