@@ -836,8 +836,11 @@ extern "C" int cbv_squares_hough(cbv_squares* s, const cbv_hough_params* prm, cb
     RC(hough_cfg(ctx, prm, s->descs, &hc));
     RC(dev_ensure(ctx, &s->d_hough, sizeof(cbv_hough_result) * CBV_MAX_SQUARES));
     RC(dev_ensure(ctx, &s->d_retry, sizeof(u32) * (1 + CBV_MAX_SQUARES)));
+    CBV_HIP(ctx, hipMemsetAsync(s->d_retry.p, 0, sizeof(u32), ctx->stream));
     RC(launch_hough(ctx, (const SquareDesc*)s->d_descs.p, s->n, (const u8*)s->d_gray.p, 0, hc, (cbv_hough_result*)s->d_hough.p, nullptr, nullptr, 1,
-                    (u32*)s->d_retry.p));
+                    (u32*)s->d_retry.p, 0));
+    RC(launch_hough_second(ctx, (const SquareDesc*)s->d_descs.p, s->n, (const u8*)s->d_gray.p, 0, hc, (cbv_hough_result*)s->d_hough.p, nullptr,
+                           (const u32*)s->d_retry.p, s->n));
     CBV_HIP(ctx, hipMemcpyAsync(out, s->d_hough.p, sizeof(cbv_hough_result) * s->n, hipMemcpyDeviceToHost, ctx->stream));
     CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return CBV_OK;
@@ -916,7 +919,6 @@ struct cbv_pipeline {
     u8* A[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
     u8* B[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
     DevBuf lane_small[MAX_LANES];
-    DevBuf lane_retry[MAX_LANES]; // HoughCircles second-pass list of the lane's current chunk (HoughCfg::retry)
     DevBuf lane_work[MAX_LANES]; // HoughCircles worklist of the lane's current chunk: count, then frame << 8 | square
     u8* enhanced = nullptr; // [max_frames] when keep_enhanced
     u8* warped = nullptr;   // [max_frames][S][S][3]
@@ -950,6 +952,7 @@ struct cbv_pipeline {
         unsigned long long seq;
         hipEvent_t lanes_ev, scan_ev;
         bool live;
+        DevBuf retry; // HoughCircles second-pass list of this run (HoughCfg::retry), frames numbered from the run's slot0
     };
     std::vector<RunRec> runs;
     unsigned long long run_seq = 0;         // sequence number of the newest run
@@ -1036,7 +1039,6 @@ extern "C" void cbv_pipeline_destroy(cbv_pipeline* p)
         if (p->B[l]) (void)hipFree(p->B[l]);
         dev_free(&p->lane_small[l]);
         dev_free(&p->lane_work[l]);
-        dev_free(&p->lane_retry[l]);
         if (p->lane_done[l]) (void)hipEventDestroy(p->lane_done[l]);
         if (p->lane_stream[l]) (void)hipStreamDestroy(p->lane_stream[l]);
     }
@@ -1048,6 +1050,7 @@ extern "C" void cbv_pipeline_destroy(cbv_pipeline* p)
     for (auto& r : p->runs) {
         (void)hipEventDestroy(r.lanes_ev);
         (void)hipEventDestroy(r.scan_ev);
+        dev_free(&r.retry);
     }
     if (p->main_done) (void)hipEventDestroy(p->main_done);
     if (p->copy_stream) {
@@ -1115,7 +1118,6 @@ extern "C" int cbv_pipeline_configure(cbv_pipeline* p, const cbv_pipeline_config
         SmallLayout SL;
         RC(small_layout(ctx, &p->lane_small[l], cfg->enhance.tiles_x * cfg->enhance.tiles_y, chunk, &SL));
         RC(dev_ensure(ctx, &p->lane_work[l], sizeof(u32) * (1 + (size_t)CBV_MAX_SQUARES * chunk)));
-        RC(dev_ensure(ctx, &p->lane_retry[l], sizeof(u32) * (1 + (size_t)CBV_MAX_SQUARES * chunk)));
         if (l > 0 && !p->lane_stream[l]) CBV_HIP(ctx, hipStreamCreateWithFlags(&p->lane_stream[l], hipStreamNonBlocking));
         if (!p->lane_done[l]) CBV_HIP(ctx, hipEventCreateWithFlags(&p->lane_done[l], hipEventDisableTiming));
     }
@@ -1326,6 +1328,23 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
     // the temporal scan (which needs every frame's statistics, in order).
     hipStream_t main_stream = ctx->stream;
     RC(join_slots(p, slot0, count)); // scans in flight that still read these slots' planes, however many runs back
+    cbv_pipeline::RunRec* rec = nullptr; // the record (and second-pass list) of this run
+    for (auto& r : p->runs)
+        if (!r.live) {
+            rec = &r;
+            break;
+        }
+    if (!rec) {
+        cbv_pipeline::RunRec r{0, 0, 0, nullptr, nullptr, false, DevBuf()};
+        CBV_HIP(ctx, hipEventCreateWithFlags(&r.lanes_ev, hipEventDisableTiming));
+        CBV_HIP(ctx, hipEventCreateWithFlags(&r.scan_ev, hipEventDisableTiming));
+        p->runs.push_back(r);
+        rec = &p->runs.back();
+    }
+    if (cfg.use_hough) {
+        RC(dev_ensure(ctx, &rec->retry, sizeof(u32) * (1 + (size_t)CBV_MAX_SQUARES * p->max_frames)));
+        CBV_HIP(ctx, hipMemsetAsync(rec->retry.p, 0, sizeof(u32), main_stream)); // before the lanes fork from this stream
+    }
     for (auto& c : p->copies) // ingest copies of these slots must have landed
         if (c.pending && ranges_overlap(slot0, count, c.s0, c.cnt)) {
             CBV_HIP(ctx, hipStreamWaitEvent(main_stream, c.ev, 0));
@@ -1377,27 +1396,13 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
         if (rc_all) break;
         if (cfg.use_hough)
             rc_all = launch_hough(ctx, (const SquareDesc*)p->d_descs.p, n, (const u8*)p->d_gray.p + p->plane_total * s0, p->plane_total,
-                                  p->hough_cfg, hres, dec, work, b, (u32*)p->lane_retry[lane].p);
+                                  p->hough_cfg, hres, dec, work, b, (u32*)rec->retry.p, s0 - slot0);
     }
     ctx->stream = main_stream;
     if (rc_all) return rc_all;
     if (!p->scan_stream) {
         CBV_HIP(ctx, hipStreamCreateWithFlags(&p->scan_stream, hipStreamNonBlocking));
         CBV_HIP(ctx, hipEventCreateWithFlags(&p->main_done, hipEventDisableTiming));
-    }
-    retire_runs(p);
-    cbv_pipeline::RunRec* rec = nullptr;
-    for (auto& r : p->runs)
-        if (!r.live) {
-            rec = &r;
-            break;
-        }
-    if (!rec) {
-        cbv_pipeline::RunRec r{0, 0, 0, nullptr, nullptr, false};
-        CBV_HIP(ctx, hipEventCreateWithFlags(&r.lanes_ev, hipEventDisableTiming));
-        CBV_HIP(ctx, hipEventCreateWithFlags(&r.scan_ev, hipEventDisableTiming));
-        p->runs.push_back(r);
-        rec = &p->runs.back();
     }
     CBV_HIP(ctx, hipEventRecord(p->main_done, main_stream));
     CBV_HIP(ctx, hipStreamWaitEvent(p->scan_stream, p->main_done, 0));
@@ -1413,6 +1418,10 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
         hipStream_t s;
         ~Restore() { c->stream = s; }
     } restore{ctx, main_stream};
+    if (cfg.use_hough) // squares whose first HoughCircles pass overflowed (normally none), before the scan reads the decisions
+        RC(launch_hough_second(ctx, (const SquareDesc*)p->d_descs.p, n, (const u8*)p->d_gray.p + p->plane_total * slot0, p->plane_total,
+                               p->hough_cfg, (cbv_hough_result*)p->d_hough.p + (size_t)CBV_MAX_SQUARES * slot0,
+                               (u8*)p->d_dec.p + (size_t)CBV_MAX_SQUARES * slot0, (const u32*)rec->retry.p, n * count));
     ScanParams sp;
     sp.n = n;
     sp.history_size = cfg.history_size;

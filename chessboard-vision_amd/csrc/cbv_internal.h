@@ -114,6 +114,7 @@ struct cbv_ctx {
     // cbv_pipeline_run points `stream` at its lanes while it enqueues.  Entry points that touch the GPU hold this lock
     // for their whole call (CBV_ENTER), so calls from several threads on one context serialise instead of corrupting it.
     std::recursive_mutex mu;
+    bool hough_lds_raised = false; // k_hough's dynamic-LDS limit was raised for this device
 };
 
 extern thread_local std::string g_cbv_err;
@@ -226,12 +227,17 @@ struct HoughCfg {
     int maxc;            // accumulator maxima / candidate circles kept per square (set by launch_hough)
     u32* retry;          // first pass: squares with more than `maxc` maxima are listed here (count, then frame << 8 | square)
                          // and done again by a second, rarely needed pass with room for every possible maximum
+    int retry_frame_base; // added to the frame index of a listed square (the second pass may cover several first passes)
 };
 // `work` (may be null = every square of every frame): work[0] = number of items, work[1 + i] = frame << 8 | square,
 // as k_squares_stats lists them; a found circle sets bit 0 of the square's `decisions` byte.
-// `retry`: device scratch of 1 + n * batch words for the second pass (see HoughCfg::retry).
+// `retry`: device list (count, then items) the first pass appends overflowing squares to (see HoughCfg::retry); the
+// caller zeroes its count before the first pass that feeds it and runs launch_hough_second over it afterwards, with
+// gray / out / decisions pointing at frame 0 of the list's frame numbering and `max_items` = its capacity.
 int launch_hough(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, size_t gray_frame_stride, HoughCfg cfg,
-                 cbv_hough_result* out, u8* decisions, const u32* work, int batch, u32* retry);
+                 cbv_hough_result* out, u8* decisions, const u32* work, int batch, u32* retry, int retry_frame_base);
+int launch_hough_second(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, size_t gray_frame_stride, HoughCfg cfg,
+                        cbv_hough_result* out, u8* decisions, const u32* retry, int max_items);
 int launch_squares_pre5_stats(cbv_ctx* ctx, const u8* src, size_t src_frame_stride, const SquareDesc* descs, int n, u8* gray,
                               size_t gray_frame_stride, const float* mean, const float* var, const u8* masks, float z_thresh,
                               cbv_sq_stats* out, int batch, u8* decisions, int want_hough, u32* hough_work,

@@ -346,7 +346,7 @@ __global__ __launch_bounds__(HG_NT) void k_hough(const SquareDesc* __restrict__ 
     if (s_over && cfg.retry) { // workgroup-uniform: hand the square to the second pass, decide nothing here
         if (tid == 0) {
             const u32 k = atomicAdd(&cfg.retry[0], 1u);
-            cfg.retry[1 + k] = ((u32)fri << 8) | (u32)sqi;
+            cfg.retry[1 + k] = ((u32)(fri + cfg.retry_frame_base) << 8) | (u32)sqi;
         }
         __syncthreads(); // s_over / s_cnt are reset at the top of the next item
         continue;
@@ -598,8 +598,10 @@ static int launch_hough_pass(cbv_ctx* ctx, const SquareDesc* descs, int n, const
     const size_t lds = hough_layout(cfg);
     if (lds > 150 * 1024)
         return cbv_fail(ctx, CBV_ERR_UNSUPPORTED, "HoughCircles stage: %dx%d squares do not fit the LDS layout", cfg.maxw, cfg.maxh);
-    if (lds > 64 * 1024) // per device and cheap: no caching across contexts
-        CBV_HIP(ctx, hipFuncSetAttribute((const void*)k_hough, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (lds > 64 * 1024 && !ctx->hough_lds_raised) { // once per context: the attribute is an upper bound
+        CBV_HIP(ctx, hipFuncSetAttribute((const void*)k_hough, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        ctx->hough_lds_raised = true;
+    }
     // as many workgroups as the chip holds at once (LDS-limited), striding over the work items
     const int per_cu = (int)(160 * 1024 / (lds + 1024)) < 2 ? ((int)(160 * 1024 / (lds + 1024)) < 1 ? 1 : (int)(160 * 1024 / (lds + 1024))) : 2;
     int grid = ctx->num_cus * per_cu;
@@ -612,35 +614,36 @@ static int launch_hough_pass(cbv_ctx* ctx, const SquareDesc* descs, int n, const
 }
 
 int launch_hough(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, size_t gray_frame_stride, HoughCfg cfg,
-                 cbv_hough_result* out, u8* decisions, const u32* work, int batch, u32* retry)
+                 cbv_hough_result* out, u8* decisions, const u32* work, int batch, u32* retry, int retry_frame_base)
 {
     if (cfg.maxw < 2 || cfg.maxh < 2 || cfg.maxw > 250 || cfg.maxh > 250)
         return cbv_fail(ctx, CBV_ERR_UNSUPPORTED, "HoughCircles stage: squares must be 2..250 px (got %dx%d)", cfg.maxw, cfg.maxh);
-    const int total = n * batch;
-    prof_begin(ctx, CBV_K_HOUGH);
     // first pass: small candidate lists (two workgroups per CU); squares that overflow them go to `retry`
     cfg.maxc = HG_MAXC;
     cfg.retry = retry;
-    if (retry) CBV_HIP(ctx, hipMemsetAsync(retry, 0, sizeof(u32), ctx->stream));
-    int rc = launch_hough_pass(ctx, descs, n, gray, gray_frame_stride, cfg, out, decisions, work, total, 1 << 30);
-    if (rc) return rc;
-    if (retry) {
-        // second pass over the listed squares only (normally none: the workgroups read a zero count and leave).
-        // No two 4-neighbours can both be maxima (a > left and a >= right exclude each other), so half the cells
-        // + 1 is room for every possible maximum; larger squares are capped by LDS and can still flag an overflow.
-        const float idp = 1.f / (cfg.dp < 1.f ? 1.f : cfg.dp);
-        const int cells = (int)ceilf(cfg.maxh * idp) * (int)ceilf(cfg.maxw * idp);
-        cfg.maxc = (cells + 1) / 2 + 1;
-        cfg.retry = nullptr;
-        for (;;) {
-            HoughCfg probe = cfg;
-            if (hough_layout(probe) <= 150 * 1024 || cfg.maxc <= HG_MAXC) break;
-            cfg.maxc = cfg.maxc * 3 / 4;
-        }
-        if (cfg.maxc < HG_MAXC) cfg.maxc = HG_MAXC;
-        rc = launch_hough_pass(ctx, descs, n, gray, gray_frame_stride, cfg, out, decisions, retry, total, 32);
-        if (rc) return rc;
-    }
+    cfg.retry_frame_base = retry_frame_base;
+    prof_begin(ctx, CBV_K_HOUGH);
+    const int rc = launch_hough_pass(ctx, descs, n, gray, gray_frame_stride, cfg, out, decisions, work, n * batch, 1 << 30);
     prof_end(ctx, CBV_K_HOUGH);
-    return CBV_OK;
+    return rc;
+}
+
+int launch_hough_second(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, size_t gray_frame_stride, HoughCfg cfg,
+                        cbv_hough_result* out, u8* decisions, const u32* retry, int max_items)
+{
+    // Second pass over the listed squares only (normally none: the workgroups read a zero count and leave).
+    // No two 4-neighbours can both be maxima (a > left and a >= right exclude each other), so half the cells
+    // + 1 is room for every possible maximum; larger squares are capped by LDS and can still flag an overflow.
+    const float idp = 1.f / (cfg.dp < 1.f ? 1.f : cfg.dp);
+    const int cells = (int)ceilf(cfg.maxh * idp) * (int)ceilf(cfg.maxw * idp);
+    cfg.maxc = (cells + 1) / 2 + 1;
+    cfg.retry = nullptr;
+    cfg.retry_frame_base = 0;
+    for (;;) {
+        HoughCfg probe = cfg;
+        if (hough_layout(probe) <= 150 * 1024 || cfg.maxc <= HG_MAXC) break;
+        cfg.maxc = cfg.maxc * 3 / 4;
+    }
+    if (cfg.maxc < HG_MAXC) cfg.maxc = HG_MAXC;
+    return launch_hough_pass(ctx, descs, n, gray, gray_frame_stride, cfg, out, decisions, retry, max_items, 32);
 }

@@ -187,3 +187,42 @@ def test_configs2_full_size_512_frames_in_flight(gpu_ctx, oracle):
         f = oracle_frame(w, h, "dim", stream_id=0, frame_idx=i)
         enh = oracle.process_pipeline(f, S.SHIPPED_PROFILE)
         assert np.array_equal(warped[i], oracle.warp_image(enh, pts)[0]), i
+
+
+def test_pipeline_hough_second_pass_on_noise_frames(gpu_ctx, oracle):
+    """White-noise frames through the whole pipeline: many squares have more accumulator maxima than the first
+    HoughCircles pass keeps, the per-run second pass redoes them before the scan, and occupancy / circles still equal
+    the oracle chain's."""
+    from chessboard_vision_amd.grid_extractor import GridExtractor
+    from chessboard_vision_amd.stream import BoardPipeline
+    from helpers import random_frame
+    from ref_logic import RefPieceDetector, detect_circle_unified
+    w, h, n = 640, 480, 5
+    pts = S.scaled_corners(w, h)
+    frames = [random_frame(w, h, 100 + i, smooth=False) for i in range(n)]
+    p = BoardPipeline(w, h, n)
+    p.configure(pts, profile={}, chunk=2, lanes=2, use_hough=2, hough_param2=6)   # 2 = HoughCircles on every non-uniform square; a low
+    # accumulator threshold makes nearly every local maximum a candidate centre
+    for i, f in enumerate(frames):
+        p.upload(i, f)
+    p.run(0, 3)
+    p.run(3, 2)
+    res = p.results(0, n)
+    det = RefPieceDetector(hough=dict(param2=6))
+    big = 0
+    for i, f in enumerate(frames):
+        warped = oracle.warp_image(oracle.process_pipeline(f, {}), pts)[0]
+        assert np.array_equal(p.download(2, i), warped)
+        sq = GridExtractor().split_board(warped)
+        ref, vis = det.detect_all_pieces(sq)
+        assert p.occupied(res[i], stable=True) == {k for k, r in ref.items() if r["has_piece"]}, i
+        assert p.occupied(res[i], stable=False) == {k for k, r in det.cached_results.items() if r["has_piece"]}, i
+        hg = p.hough(i)
+        for roi, (r, c) in enumerate(p.rois_rc):
+            g = oracle.square_preprocess(sq[(c, 7 - r)], 5)
+            if hg[roi].flags & 2:  # skipped: uniform square
+                continue
+            found, center, radius, kind, circles = detect_circle_unified(g, param2=6)
+            assert hg[roi].flags == 0 and hg[roi].n_circles == len(circles) and bool(hg[roi].found) == found, (i, roi)
+            big += hg[roi].n_centres > 512
+    assert big > 0, "no square needed the second pass: the test does not exercise it"
