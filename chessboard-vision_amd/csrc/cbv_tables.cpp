@@ -28,30 +28,36 @@ void build_static_tabs(StaticTabs* t)
         t->sdiv[i] = round_d((255 << 12) / (1. * i));
         t->hdiv[i] = round_d((180 << 12) / (6. * i));
     }
+    // cv::initLabTabs evaluates the Lab tables in softfloat (IEEE binary32, one rounding per operation; the gamma
+    // curves in softdouble, narrowed to float before scaling; mulAdd is a fused multiply-add): same steps in float.
+    const float k255 = 255.0f, gamma_scale = (float)(255 * (1 << GAMMA_SHIFT));
     for (int i = 0; i < 256; i++) {
-        double x = i / 255.0;
-        double g = x <= 0.04045 ? x / 12.92 : pow((x + 0.055) / 1.055, 2.4);
-        t->gamma[i] = (u16)round_d(255.0 * (1 << GAMMA_SHIFT) * g);
+        const double xd = (double)((float)i / k255);
+        const double lin = xd <= 0.04045 ? xd / 12.92 : pow((xd + 0.055) / (1.0 + 0.055), 2.4);
+        t->gamma[i] = (u16)round_f(gamma_scale * (float)lin);
     }
+    const float cbrt_step = 1.0f / (k255 * (float)(1 << GAMMA_SHIFT)), cbrt_gain = (float)(1 << LAB_SHIFT2);
+    const float lin_limit = 216.0f / 24389.0f, lin_slope = 841.0f / 108.0f, lin_offset = 16.0f / 116.0f;
     for (int i = 0; i < LAB_CBRT_TAB_SIZE_B; i++) {
-        double x = i / (255.0 * (1 << GAMMA_SHIFT));
-        double f = x < 216.0 / 24389.0 ? x * (841.0 / 108.0) + 16.0 / 116.0 : cbrt(x);
-        t->cbrt[i] = (u16)round_d((1 << LAB_SHIFT2) * f);
+        const float x = cbrt_step * (float)i;
+        const float fx = x < lin_limit ? fmaf(x, lin_slope, lin_offset) : (float)cbrt((double)x);
+        t->cbrt[i] = (u16)round_f(cbrt_gain * fx);
     }
+    const float inv_step = 1.0f / (float)(INV_GAMMA_TAB_SIZE - 1);
     for (int i = 0; i < INV_GAMMA_TAB_SIZE; i++) {
-        double x = i / (double)(INV_GAMMA_TAB_SIZE - 1);
-        double g = x <= 0.0031308 ? x * 12.92 : 1.055 * pow(x, 1.0 / 2.4) - 0.055;
-        t->inv_gamma[i] = (u16)round_d(255.0 * g);
+        const double xd = (double)(inv_step * (float)i);
+        const double enc = xd <= 0.0031308 ? xd * 12.92 : pow(xd, 1.0 / 2.4) * (1.0 + 0.055) - 0.055;
+        t->inv_gamma[i] = (u16)round_f(k255 * (float)enc);
     }
     for (int i = 0; i < 256; i++) {
         int y, ify;
-        if (i <= 20) {
-            y = round_d((double)(i * LAB_BASE * 20 * 9) / (double)(17 * 29 * 29 * 29));
-            ify = round_d(LAB_BASE * (16.0 / 116.0 + (double)(i * 5) / (double)(3 * 17 * 29)));
+        if (i <= 20) { // L <= 8: the linear piece of L -> Y
+            y = round_f((float)(i * LAB_BASE * 20 * 9) / (float)(17 * 29 * 29 * 29));
+            ify = round_f((float)LAB_BASE * (16.0f / 116.0f + (float)(i * 5) / (float)(3 * 17 * 29)));
         } else {
-            double fy = (double)(i * 100 * LAB_BASE) / (double)(255 * 116) + (double)(16 * LAB_BASE) / 116.0;
-            ify = round_d(fy);
-            y = round_d(fy * fy * fy / ((double)LAB_BASE * LAB_BASE));
+            const float fy = (float)(i * 100 * LAB_BASE) / (float)(255 * 116) + (float)(16 * LAB_BASE) / 116.0f;
+            ify = round_f(fy);
+            y = round_f(fy * fy * fy / (float)(LAB_BASE * LAB_BASE));
         }
         t->lab_yf[i * 2] = (u16)y;
         t->lab_yf[i * 2 + 1] = (u16)ify;

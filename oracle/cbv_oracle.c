@@ -288,30 +288,47 @@ static const double kXYZ2RGB[9] = {3.240479, -1.53715, -0.498535, -0.969256, 1.8
 static void lab_init(void)
 {
     if (g_lab_init) return;
+    /* OpenCV's initLabTabs computes these tables in `softfloat` = IEEE binary32, one rounding per operation
+     * (softdouble inside applyGamma / applyInvGamma), mulAdd = fmaf.  Same operations, same order, in float here.
+     * Against an all-double evaluation this changes 4 of the 3072 cube-root entries by one unit (the float
+     * rounding of x = scale * i) and nothing else.  cv::cbrt(softfloat) itself is OpenCV's own polynomial
+     * algorithm; the correctly rounded cbrt stands in for it (PARITY UNPINNED like every OpenCV-side number). */
+    const float f255 = 255.0f;
+    const float int_scale = (float)(255 * (1 << GAMMA_SHIFT));
     for (int i = 0; i < 256; i++) {
-        double x = i / 255.0;
-        double g = x <= 0.04045 ? x / 12.92 : pow((x + 0.055) / 1.055, 2.4);
-        g_srgb_gamma[i] = (u16)cv_round_d(255.0 * (1 << GAMMA_SHIFT) * g);
+        const float x = (float)i / f255;
+        const double xd = (double)x;
+        const double g = xd <= 0.04045 ? xd / 12.92 : pow((xd + 0.055) / (1.0 + 0.055), 2.4);
+        g_srgb_gamma[i] = (u16)cv_round_f(int_scale * (float)g);
     }
-    for (int i = 0; i < LAB_CBRT_TAB_SIZE_B; i++) {
-        double x = i / (255.0 * (1 << GAMMA_SHIFT));
-        double f = x < 216.0 / 24389.0 ? x * (841.0 / 108.0) + 16.0 / 116.0 : cbrt(x);
-        g_lab_cbrt[i] = (u16)cv_round_d((1 << LAB_SHIFT2) * f);
+    {
+        const float lthresh = 216.0f / 24389.0f, lscale = 841.0f / 108.0f, lbias = 16.0f / 116.0f;
+        const float cb_scale = 1.0f / (f255 * (float)(1 << GAMMA_SHIFT));
+        const float lshift2 = (float)(1 << LAB_SHIFT2);
+        for (int i = 0; i < LAB_CBRT_TAB_SIZE_B; i++) {
+            const float x = cb_scale * (float)i;
+            const float f = x < lthresh ? fmaf(x, lscale, lbias) : (float)cbrt((double)x);
+            g_lab_cbrt[i] = (u16)cv_round_f(lshift2 * f);
+        }
     }
-    for (int i = 0; i < INV_GAMMA_TAB_SIZE; i++) {
-        double x = i / (double)(INV_GAMMA_TAB_SIZE - 1);
-        double g = x <= 0.0031308 ? x * 12.92 : 1.055 * pow(x, 1.0 / 2.4) - 0.055;
-        g_inv_gamma[i] = (u16)cv_round_d(255.0 * g);
+    {
+        const float inv_scale = 1.0f / (float)(INV_GAMMA_TAB_SIZE - 1);
+        for (int i = 0; i < INV_GAMMA_TAB_SIZE; i++) {
+            const float x = inv_scale * (float)i;
+            const double xd = (double)x;
+            const double g = xd <= 0.0031308 ? xd * 12.92 : pow(xd, 1.0 / 2.4) * (1.0 + 0.055) - 0.055;
+            g_inv_gamma[i] = (u16)cv_round_f(f255 * (float)g);
+        }
     }
     for (int i = 0; i < 256; i++) {
         int y, ify;
         if (i <= 20) {
-            y = cv_round_d((double)(i * LAB_BASE * 20 * 9) / (double)(17 * 29 * 29 * 29));
-            ify = cv_round_d(LAB_BASE * (16.0 / 116.0 + (double)(i * 5) / (double)(3 * 17 * 29)));
+            y = cv_round_f((float)(i * LAB_BASE * 20 * 9) / (float)(17 * 29 * 29 * 29));
+            ify = cv_round_f((float)LAB_BASE * (16.0f / 116.0f + (float)(i * 5) / (float)(3 * 17 * 29)));
         } else {
-            double fy = (double)(i * 100 * LAB_BASE) / (double)(255 * 116) + (double)(16 * LAB_BASE) / 116.0;
-            ify = cv_round_d(fy);
-            y = cv_round_d(fy * fy * fy / ((double)LAB_BASE * LAB_BASE));
+            const float fy = (float)(i * 100 * LAB_BASE) / (float)(255 * 116) + (float)(16 * LAB_BASE) / 116.0f;
+            ify = cv_round_f(fy);
+            y = cv_round_f(fy * fy * fy / (float)(LAB_BASE * LAB_BASE));
         }
         g_lab_to_yf[i * 2] = y;
         g_lab_to_yf[i * 2 + 1] = ify;
@@ -938,6 +955,18 @@ ORC_API void orc_warp_perspective(const u8* src, int sw, int sh, int sstride, co
         }
     }
 }
+
+/* bench.py's cpu_baseline leg times the oracle at 1 thread and at all cores: OpenMP team size of the calling thread */
+#ifdef _OPENMP
+#include <omp.h>
+ORC_API int orc_set_threads(int n)
+{
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+}
+#else
+ORC_API int orc_set_threads(int n) { (void)n; return 1; }
+#endif
 
 /* A14 cv2.rotate(ROTATE_180) (game_session.py:126) */
 ORC_API void orc_rotate180(const u8* src, int w, int h, int sstride, int cn, u8* dst, int dstride)

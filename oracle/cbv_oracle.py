@@ -36,6 +36,12 @@ def lib():
     return _lib
 
 
+def set_threads(n):
+    """OpenMP team size for later oracle calls from this thread (0 = only query); returns the size in effect."""
+    lib().orc_set_threads.restype = C.c_int
+    return lib().orc_set_threads(int(n))
+
+
 class Profile(C.Structure):
     _fields_ = [("hue_shift", C.c_double), ("sat_scale", C.c_double), ("val_scale", C.c_double),
                 ("contrast", C.c_double), ("brightness", C.c_double), ("radical_mode", C.c_int),

@@ -63,3 +63,21 @@ def test_algorithmic_bytes_match_survey():
     assert per["k_bilateral"] == 2 * 6220800
     _, total4k = bench.algorithmic_bytes(3840, 2160)
     assert abs(total4k - 265479684) <= 16
+
+
+def _run_bench(args, env_extra, timeout=180):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_refuses_a_rank_count_it_was_not_launched_with():
+    """`--gpus N` must be the number of ranks: a launcher mismatch is an error, never a silent single-rank run that
+    prints n_gpus: 1 (without a launcher bench.py starts the N ranks itself when the node has N GPUs)."""
+    r = _run_bench(["--gpus", "2"], {"WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=1 but --gpus 2" in r.stderr and r.stdout.strip() == ""
+    r = _run_bench(["--gpus", "4"], {})          # no launcher and no GPUs here: refuses before touching anything
+    assert r.returncode != 0 and "--gpus 4 but only" in r.stderr and r.stdout.strip() == ""
+    r = _run_bench(["--gpus", "0"], {})
+    assert r.returncode != 0
