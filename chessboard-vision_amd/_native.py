@@ -152,6 +152,7 @@ def load():
         "cbv_kernel_name": (C.c_char_p, [i32]),
         "cbv_apply_color_profile": (i32, [vp, u8p, i32, i32, i32, P(ColorProfile), u8p, i32]),
         "cbv_correct_lighting": (i32, [vp, u8p, i32, i32, i32, dbl, i32, i32, u8p, i32]),
+        "cbv_clahe_apply": (i32, [vp, u8p, i32, i32, i32, dbl, i32, i32, u8p, i32]),
         "cbv_reduce_noise": (i32, [vp, u8p, i32, i32, i32, i32, dbl, dbl, u8p, i32]),
         "cbv_sharpen": (i32, [vp, u8p, i32, i32, i32, vp, u8p, i32]),
         "cbv_normalize_intensity": (i32, [vp, u8p, i32, i32, i32, u8p, i32]),

@@ -1,7 +1,8 @@
-"""warp_image / reorder — drop-in for board_detection.py:49-71.
+"""warp_image / reorder / find_chessboard_corners — drop-in for board_detection.py:4-71.
 
-Corner detection and overlay drawing of the reference module are calibration/UI
-code and are not part of this package."""
+warp_image and reorder are the hot path's; find_chessboard_corners is the widening row f3 (pixel
+stages on the GPU, contour following on the host inside the same library).  The overlay-drawing helpers of the
+reference module (board_detection.py:74-146) are UI code and are not part of this package."""
 import ctypes as C
 
 import numpy as np

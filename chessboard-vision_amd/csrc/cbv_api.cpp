@@ -364,6 +364,21 @@ extern "C" int cbv_correct_lighting(cbv_ctx* ctx, const uint8_t* bgr, int w, int
     return download(ctx, ctx->b.p, out, w * 3, h, out_stride);
 }
 
+extern "C" int cbv_clahe_apply(cbv_ctx* ctx, const uint8_t* gray, int w, int h, int stride, double clip_limit, int tiles_x,
+                               int tiles_y, uint8_t* out, int out_stride)
+{
+    RC(check_img(ctx, gray, w, h, stride, 1, "cbv_clahe_apply"));
+    if (!out || tiles_x <= 0 || tiles_y <= 0 || tiles_x > 64 || tiles_y > 64) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_clahe_apply: bad arguments");
+    CBV_ENTER(ctx);
+    RC(upload(ctx, &ctx->in, gray, w, h, stride));
+    RC(dev_ensure(ctx, &ctx->a, ((size_t)w * h + 255) & ~(size_t)255));
+    ClaheGeom cg = clahe_geom(w, h, clip_limit, tiles_x, tiles_y);
+    SmallLayout S;
+    RC(small_layout(ctx, &ctx->small, tiles_x * tiles_y, 1, &S));
+    RC(launch_clahe_gray(ctx, (const u8*)ctx->in.p, w, h, w, cg, S.aux, S.luts, (u8*)ctx->a.p));
+    return download(ctx, ctx->a.p, out, w, h, out_stride);
+}
+
 extern "C" int cbv_reduce_noise(cbv_ctx* ctx, const uint8_t* bgr, int w, int h, int stride, int d, double sigma_color,
                                 double sigma_space, uint8_t* out, int out_stride)
 {

@@ -129,3 +129,56 @@ int launch_threshold(cbv_ctx* ctx, const u8* blur, u8* binary, const u32* aux, i
     CBV_HIP(ctx, hipGetLastError());
     return CBV_OK;
 }
+
+// ---------------------------------------------------------------------------
+// cv2.CLAHE.apply on a single-channel image (the `clahe` attribute of ImageEnhancer, frame_enhancer.py:36,114):
+// per-tile histograms of the image extended by REFLECT_101 to a multiple of the tile grid, k_clahe_lut (shared with
+// correct_lighting), then the same float bilinear interpolation between the four neighbouring tile LUTs as
+// k_clahe_apply.  Small and simple on purpose: the hot path applies CLAHE inside k_color_lab_hist / k_clahe_apply.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_clahe_gray_hist(const u8* __restrict__ src, int w, int h, int stride, ClaheGeom cg,
+                                                          u32* __restrict__ aux)
+{
+    __shared__ u32 hist[256];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int tile = blockIdx.x, tx = tile % cg.tiles_x, ty = tile / cg.tiles_x;
+    const int n = cg.tw * cg.th;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int r = i / cg.tw, c = i - r * cg.tw;
+        const int sy = d_reflect101(ty * cg.th + r, h), sx = d_reflect101(tx * cg.tw + c, w);
+        atomicAdd(&hist[src[(size_t)sy * stride + sx]], 1u);
+    }
+    __syncthreads();
+    aux[(size_t)tile * 256 + threadIdx.x] = hist[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void k_clahe_gray_apply(const u8* __restrict__ src, u8* __restrict__ dst, int w, int h, int stride,
+                                                           ClaheGeom cg, const u8* __restrict__ luts)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w || y >= h) return;
+    const float inv_th = 1.0f / cg.th, inv_tw = 1.0f / cg.tw;
+    const float tyf = (float)y * inv_th - 0.5f, txf = (float)x * inv_tw - 0.5f;
+    const int ty1 = d_floor_f(tyf), tx1 = d_floor_f(txf);
+    const float ya = tyf - (float)ty1, ya1 = 1.0f - ya, xa = txf - (float)tx1, xa1 = 1.0f - xa;
+    const int r1 = max(ty1, 0), r2 = min(ty1 + 1, cg.tiles_y - 1), c1 = max(tx1, 0), c2 = min(tx1 + 1, cg.tiles_x - 1);
+    const int v = src[(size_t)y * stride + x];
+    const u8* l1 = luts + (size_t)r1 * cg.tiles_x * 256;
+    const u8* l2 = luts + (size_t)r2 * cg.tiles_x * 256;
+    const float ra = (float)l1[c1 * 256 + v] * xa1 + (float)l1[c2 * 256 + v] * xa;
+    const float rb = (float)l2[c1 * 256 + v] * xa1 + (float)l2[c2 * 256 + v] * xa;
+    dst[(size_t)y * w + x] = (u8)__builtin_amdgcn_cvt_pk_u8_f32(ra * ya1 + rb * ya, 0, 0u); // round-half-even + saturate
+}
+
+int launch_clahe_gray(cbv_ctx* ctx, const u8* src, int w, int h, int stride, ClaheGeom cg, u32* aux, u8* luts, u8* dst)
+{
+    const int tiles = cg.tiles_x * cg.tiles_y;
+    hipLaunchKernelGGL(k_clahe_gray_hist, dim3(tiles), dim3(256), 0, ctx->stream, src, w, h, stride, cg, aux);
+    CBV_HIP(ctx, hipGetLastError());
+    const int rc = launch_clahe_lut(ctx, aux, luts, cg, 1);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_clahe_gray_apply, dim3((w + 255) / 256, h), dim3(256), 0, ctx->stream, src, dst, w, h, stride, cg, luts);
+    CBV_HIP(ctx, hipGetLastError());
+    return CBV_OK;
+}

@@ -14,14 +14,26 @@ from . import _native as N
 
 
 class _ClaheParams:
-    """Stand-in for the cv2.CLAHE handle kept in `self.clahe`
-    (frame_enhancer.py:36): carries the two parameters and applies CLAHE to a
-    single-channel image through the device path."""
+    """Stand-in for the cv2.CLAHE handle kept in `self.clahe` (frame_enhancer.py:36): carries clipLimit /
+    tileGridSize with cv2's accessor names, and `apply(gray)` runs CLAHE on a single-channel uint8 image on
+    the device (cbv_clahe_apply), as `self.clahe.apply(l)` does inside correct_lighting (frame_enhancer.py:114)."""
 
     def __init__(self, owner, clip_limit, tile_grid_size):
         self._owner = owner
         self.clipLimit = float(clip_limit)
         self.tileGridSize = (int(tile_grid_size[0]), int(tile_grid_size[1]))
+
+    def apply(self, src):
+        a = np.asarray(src)
+        if a.dtype != np.uint8 or a.ndim != 2:
+            raise ValueError("CLAHE.apply on the HIP path takes a single-channel uint8 image, got %s %s" % (a.dtype, a.shape))
+        if a.strides[1] != 1:
+            a = np.ascontiguousarray(a)
+        out = np.empty(a.shape, np.uint8)
+        c = self._owner._ctx
+        tx, ty = self.tileGridSize
+        c.check(c.lib.cbv_clahe_apply(c.h, N.ptr(a), a.shape[1], a.shape[0], a.strides[0], self.clipLimit, tx, ty, N.ptr(out), out.strides[0]))
+        return out
 
     def getClipLimit(self):
         return self.clipLimit

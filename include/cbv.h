@@ -139,6 +139,10 @@ CBV_API int cbv_apply_color_profile(cbv_ctx* ctx, const uint8_t* bgr, int w, int
 /* correct_lighting, frame_enhancer.py:101-120 */
 CBV_API int cbv_correct_lighting(cbv_ctx* ctx, const uint8_t* bgr, int w, int h, int stride, double clip_limit,
                          int tiles_x, int tiles_y, uint8_t* out, int out_stride);
+/* cv2.CLAHE.apply on a single-channel 8-bit image: what `ImageEnhancer.clahe.apply(l)` does inside correct_lighting
+ * (frame_enhancer.py:36,114), callable on its own because `clahe` is a public attribute of the class. */
+CBV_API int cbv_clahe_apply(cbv_ctx* ctx, const uint8_t* gray, int w, int h, int stride, double clip_limit, int tiles_x,
+                            int tiles_y, uint8_t* out, int out_stride);
 /* reduce_noise, frame_enhancer.py:122-131 */
 CBV_API int cbv_reduce_noise(cbv_ctx* ctx, const uint8_t* bgr, int w, int h, int stride, int d, double sigma_color,
                      double sigma_space, uint8_t* out, int out_stride);

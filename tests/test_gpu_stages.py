@@ -524,3 +524,98 @@ def test_randomised_warps(gpu_ctx, oracle, seed):
     want = oracle.warp_perspective(f, M, (dw, dh))
     assert_same(warp_perspective(f, M, (dw, dh)), want, "warp %dx%d -> %dx%d" % (w, h, dw, dh))
     assert_same(warp_perspective(f, M, (dw, dh), rot180=True), oracle.rotate180(want), "warp + rot180")
+
+
+@pytest.mark.parametrize("shape", [(480, 640), (203, 317), (61, 97)])
+def test_clahe_handle_apply_on_single_channel(gpu_ctx, oracle, shape):
+    """ImageEnhancer.clahe is a cv2.CLAHE in the reference (frame_enhancer.py:36) and correct_lighting calls
+    self.clahe.apply(l) (:114): the stand-in's apply() gives the oracle's CLAHE on gray images, non-divisible grids
+    and changed parameters included, and correct_lighting == BGR2LAB -> clahe.apply(L) -> LAB2BGR composed by hand."""
+    from chessboard_vision_amd.frame_enhancer import ImageEnhancer
+    rng = np.random.default_rng(shape[0])
+    yy, xx = np.mgrid[:shape[0], :shape[1]]
+    gray = np.clip(96 + 70 * np.sin(xx / 23.0) * np.cos(yy / 17.0) + rng.normal(0, 9, shape), 0, 255).astype(np.uint8)
+    e = ImageEnhancer()
+    assert np.array_equal(e.clahe.apply(gray), oracle.clahe(gray, 3.0, (8, 8)))
+    e.clahe.setClipLimit(1.5)
+    e.clahe.setTilesGridSize((5, 7))
+    assert np.array_equal(e.clahe.apply(gray), oracle.clahe(gray, 1.5, (5, 7)))
+    assert np.array_equal(e.clahe.apply(gray[:, ::2]), oracle.clahe(np.ascontiguousarray(gray[:, ::2]), 1.5, (5, 7)))  # strided view
+    e2 = ImageEnhancer()
+    bgr = np.stack([gray, np.roll(gray, 5, 0), 255 - gray], axis=-1)
+    lab = oracle.bgr2lab(bgr)
+    lab2 = lab.copy()
+    lab2[..., 0] = e2.clahe.apply(np.ascontiguousarray(lab[..., 0]))
+    assert np.array_equal(e2.correct_lighting(bgr), oracle.lab2bgr(lab2))
+    with pytest.raises(ValueError):
+        e.clahe.apply(bgr)
+
+
+def test_piece_detector_reads_settings_from_cwd(gpu_ctx, tmp_path, monkeypatch):
+    """piece_detector.py:52-68: piece_detector_settings.json in the working directory overrides the radius ratios
+    (percent -> ratio); other keys are ignored (hough_param2 of the shipped file does NOT reach HoughCircles: the
+    effective value stays the getattr default 25, piece_detector.py:229); a broken file is reported and ignored."""
+    import json
+    from chessboard_vision_amd.piece_detector import PieceDetector
+    monkeypatch.chdir(tmp_path)
+    d = PieceDetector()
+    assert (d.min_radius_ratio, d.max_radius_ratio) == (0.20, 0.55)
+    shipped = {"min_radius": 25, "max_radius": 55, "hough_param1": 100, "hough_param2": 30, "small_min": 12, "small_max": 25,
+               "knight_aspect_max": 250, "center_diff_thresh": 40}   # piece_detector_settings.json of the reference
+    (tmp_path / "piece_detector_settings.json").write_text(json.dumps(shipped))
+    d = PieceDetector()
+    assert (d.min_radius_ratio, d.max_radius_ratio) == (0.25, 0.55)
+    assert not hasattr(d, "hough_param2") and d._hough_kwargs()["param2"] == 25 and d._hough_kwargs()["param1"] == 100
+    (tmp_path / "piece_detector_settings.json").write_text(json.dumps({"max_radius": 40}))
+    d = PieceDetector()
+    assert (d.min_radius_ratio, d.max_radius_ratio) == (0.20, 0.40)
+    (tmp_path / "piece_detector_settings.json").write_text("{not json")
+    d = PieceDetector()
+    assert (d.min_radius_ratio, d.max_radius_ratio) == (0.20, 0.55)
+    (tmp_path / "color_profile.json").write_text(json.dumps({"hue_shift": 3}))
+    from chessboard_vision_amd.frame_enhancer import ImageEnhancer
+    assert ImageEnhancer().profile == {"hue_shift": 3}
+
+
+def test_calls_from_several_threads_share_one_context_safely(gpu_ctx, oracle):
+    """The reference session is multi-threaded (Lichess stream thread + board_lock) and ctypes releases the GIL:
+    entry points hold the context's lock for their whole call, so concurrent callers serialise instead of sharing
+    the context's scratch buffers and stream mid-call."""
+    import threading
+    from chessboard_vision_amd import synth as S
+    from chessboard_vision_amd.frame_enhancer import ImageEnhancer
+    from chessboard_vision_amd.stream import BoardPipeline
+    f1, f2 = random_frame(320, 240, 1), random_frame(400, 300, 2)
+    want1, want2 = oracle.process_pipeline(f1, S.SHIPPED_PROFILE), oracle.bilateral(f2)
+    e = ImageEnhancer()
+    e.profile = S.SHIPPED_PROFILE
+    p = BoardPipeline(320, 240, 4)
+    p.configure(S.scaled_corners(320, 240), profile={})
+    p.synth(0, 4)
+    p.run(0, 4)
+    want3 = [(r.raw_occupied, r.stable_occupied) for r in p.results(0, 4)]
+    errs = []
+
+    def w1():
+        for _ in range(6):
+            if not np.array_equal(e.process_pipeline(f1), want1):
+                errs.append("process_pipeline")
+
+    def w2():
+        for _ in range(6):
+            if not np.array_equal(e.reduce_noise(f2), want2):
+                errs.append("reduce_noise")
+
+    def w3():
+        for _ in range(6):
+            p.reset_state()
+            p.run(0, 4)
+            if [(r.raw_occupied, r.stable_occupied) for r in p.results(0, 4)] != want3:
+                errs.append("pipeline")
+
+    ts = [threading.Thread(target=f) for f in (w1, w2, w3)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
