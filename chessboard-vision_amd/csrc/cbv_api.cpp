@@ -302,20 +302,25 @@ static int download(cbv_ctx* ctx, const void* src, u8* dst, int wbytes, int h, i
 struct SmallLayout {
     u32* aux;
     u8* luts;
+    u32* packed; // CLAHE corner words (k_clahe_lut -> k_clahe_apply), null when not reserved
     u8* norm_lut;
 };
 
-static int small_layout(cbv_ctx* ctx, DevBuf* buf, int tiles, int batch, SmallLayout* L)
+// tiles_x / tiles_y > 0 also reserve the packed CLAHE corner words ([batch][tiles_y + 1][tiles_x + 1][256] u32)
+static int small_layout(cbv_ctx* ctx, DevBuf* buf, int tiles, int batch, SmallLayout* L, int tiles_x = 0, int tiles_y = 0)
 {
     size_t aux_b = aux_words(tiles) * 4 * batch;
     aux_b = (aux_b + 255) & ~(size_t)255;
     size_t lut_b = ((size_t)tiles * 256 * batch + 255) & ~(size_t)255;
-    size_t nl_b = (size_t)256 * batch;
-    int rc = dev_ensure(ctx, buf, aux_b + lut_b + nl_b);
+    size_t nl_b = ((size_t)256 * batch + 255) & ~(size_t)255;
+    size_t pk_b = (size_t)(tiles_x + 1) * (tiles_y + 1) * 1024 * batch;
+    if (tiles_x <= 0 || tiles_y <= 0) pk_b = 0;
+    int rc = dev_ensure(ctx, buf, aux_b + lut_b + nl_b + pk_b);
     if (rc) return rc;
     L->aux = (u32*)buf->p;
     L->luts = (u8*)buf->p + aux_b;
     L->norm_lut = (u8*)buf->p + aux_b + lut_b;
+    L->packed = pk_b ? (u32*)((u8*)buf->p + aux_b + lut_b + nl_b) : nullptr;
     return CBV_OK;
 }
 
@@ -356,11 +361,11 @@ extern "C" int cbv_correct_lighting(cbv_ctx* ctx, const uint8_t* bgr, int w, int
     ClaheGeom cg = clahe_geom(w, h, clip_limit, tiles_x, tiles_y);
     int tiles = tiles_x * tiles_y;
     SmallLayout S;
-    RC(small_layout(ctx, &ctx->small, tiles, 1, &S));
+    RC(small_layout(ctx, &ctx->small, tiles, 1, &S, tiles_x, tiles_y));
     RC(launch_reset_aux(ctx, S.aux, tiles, 1));
     RC(launch_color_lab_hist(ctx, (const u8*)ctx->in.p, (u8*)ctx->a.p, S.aux, g, cg, 1, 0, 1));
-    RC(launch_clahe_lut(ctx, S.aux, S.luts, cg, 1));
-    RC(launch_clahe_apply(ctx, (const u8*)ctx->a.p, S.luts, (u8*)ctx->b.p, g, cg, 1));
+    RC(launch_clahe_lut(ctx, S.aux, S.luts, cg, 1, S.packed));
+    RC(launch_clahe_apply(ctx, (const u8*)ctx->a.p, S.packed, (u8*)ctx->b.p, g, cg, 1));
     return download(ctx, ctx->b.p, out, w * 3, h, out_stride);
 }
 
@@ -529,8 +534,9 @@ static int enhance_dev(cbv_ctx* ctx, const u8* src, u8* A, u8* B, Geom g, const 
     int tiles = P->tiles_x * P->tiles_y;
     RC(launch_reset_aux(ctx, S.aux, tiles, batch));
     RC(launch_color_lab_hist(ctx, src, A, S.aux, g, cg, batch, P->profile.enabled ? 1 : 0, 1));
-    RC(launch_clahe_lut(ctx, S.aux, S.luts, cg, batch));
-    RC(launch_clahe_apply(ctx, A, S.luts, B, g, cg, batch));
+    if (!S.packed) return cbv_fail(ctx, CBV_ERR_STATE, "enhance_dev: the small-buffer layout lacks the packed CLAHE words");
+    RC(launch_clahe_lut(ctx, S.aux, S.luts, cg, batch, S.packed));
+    RC(launch_clahe_apply(ctx, A, S.packed, B, g, cg, batch));
     RC(launch_bilateral(ctx, B, A, g, batch));
     RC(launch_sharpen(ctx, A, B, S.aux, tiles, g, P->sharpen_kernel, batch));
     RC(launch_norm_lut(ctx, S.aux, tiles, S.norm_lut, batch));
@@ -564,7 +570,7 @@ extern "C" int cbv_process_pipeline(cbv_ctx* ctx, const uint8_t* bgr, int w, int
     RC(dev_ensure(ctx, &ctx->a, g.frame_stride));
     RC(dev_ensure(ctx, &ctx->b, g.frame_stride));
     SmallLayout S;
-    RC(small_layout(ctx, &ctx->small, params->tiles_x * params->tiles_y, 1, &S));
+    RC(small_layout(ctx, &ctx->small, params->tiles_x * params->tiles_y, 1, &S, params->tiles_x, params->tiles_y));
     u8* res = nullptr;
     RC(enhance_dev(ctx, (const u8*)ctx->in.p, (u8*)ctx->a.p, (u8*)ctx->b.p, g, params, S, 1, false, &res));
     return download(ctx, res, out, w * 3, h, out_stride);
@@ -1131,7 +1137,7 @@ extern "C" int cbv_pipeline_configure(cbv_pipeline* p, const cbv_pipeline_config
         CBV_HIP(ctx, hipMalloc((void**)&p->A[l], p->g.frame_stride * chunk + 256));
         CBV_HIP(ctx, hipMalloc((void**)&p->B[l], p->g.frame_stride * chunk + 256));
         SmallLayout SL;
-        RC(small_layout(ctx, &p->lane_small[l], cfg->enhance.tiles_x * cfg->enhance.tiles_y, chunk, &SL));
+        RC(small_layout(ctx, &p->lane_small[l], cfg->enhance.tiles_x * cfg->enhance.tiles_y, chunk, &SL, cfg->enhance.tiles_x, cfg->enhance.tiles_y));
         RC(dev_ensure(ctx, &p->lane_work[l], sizeof(u32) * (1 + (size_t)CBV_MAX_SQUARES * chunk)));
         if (l > 0 && !p->lane_stream[l]) CBV_HIP(ctx, hipStreamCreateWithFlags(&p->lane_stream[l], hipStreamNonBlocking));
         if (!p->lane_done[l]) CBV_HIP(ctx, hipEventCreateWithFlags(&p->lane_done[l], hipEventDisableTiming));
@@ -1374,7 +1380,7 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
         const int lane = ci % p->n_lanes;
         ctx->stream = lane == 0 ? main_stream : p->lane_stream[lane];
         SmallLayout SL;
-        rc_all = small_layout(ctx, &p->lane_small[lane], cfg.enhance.tiles_x * cfg.enhance.tiles_y, p->chunk, &SL);
+        rc_all = small_layout(ctx, &p->lane_small[lane], cfg.enhance.tiles_x * cfg.enhance.tiles_y, p->chunk, &SL, cfg.enhance.tiles_x, cfg.enhance.tiles_y);
         if (rc_all) break;
         const int b = std::min(p->chunk, slot0 + count - s0);
         const u8* src = p->frames + p->g.frame_stride * s0;

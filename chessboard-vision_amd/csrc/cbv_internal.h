@@ -177,8 +177,8 @@ __host__ __device__ static inline size_t aux_words(int tiles) { return (size_t)t
 int launch_reset_aux(cbv_ctx* ctx, u32* aux, int tiles, int batch);
 int launch_color_lab_hist(cbv_ctx* ctx, const u8* src, u8* lab, u32* aux, Geom g, ClaheGeom cg, int batch,
                           int do_profile, int do_lab);
-int launch_clahe_lut(cbv_ctx* ctx, const u32* aux, u8* luts, ClaheGeom cg, int batch);
-int launch_clahe_apply(cbv_ctx* ctx, const u8* lab, const u8* luts, u8* dst, Geom g, ClaheGeom cg, int batch);
+int launch_clahe_lut(cbv_ctx* ctx, const u32* aux, u8* luts, ClaheGeom cg, int batch, u32* packed);
+int launch_clahe_apply(cbv_ctx* ctx, const u8* lab, const u32* packed, u8* dst, Geom g, ClaheGeom cg, int batch);
 int launch_clahe_gray(cbv_ctx* ctx, const u8* src, int w, int h, int stride, ClaheGeom cg, u32* aux, u8* luts, u8* dst);
 int launch_bilateral(cbv_ctx* ctx, const u8* src, u8* dst, Geom g, int batch);
 int launch_sharpen(cbv_ctx* ctx, const u8* src, u8* dst, u32* aux, int tiles, Geom g, const float* k9, int batch);

@@ -176,7 +176,7 @@ int launch_clahe_gray(cbv_ctx* ctx, const u8* src, int w, int h, int stride, Cla
     const int tiles = cg.tiles_x * cg.tiles_y;
     hipLaunchKernelGGL(k_clahe_gray_hist, dim3(tiles), dim3(256), 0, ctx->stream, src, w, h, stride, cg, aux);
     CBV_HIP(ctx, hipGetLastError());
-    const int rc = launch_clahe_lut(ctx, aux, luts, cg, 1);
+    const int rc = launch_clahe_lut(ctx, aux, luts, cg, 1, nullptr);
     if (rc) return rc;
     hipLaunchKernelGGL(k_clahe_gray_apply, dim3((w + 255) / 256, h), dim3(256), 0, ctx->stream, src, dst, w, h, stride, cg, luts);
     CBV_HIP(ctx, hipGetLastError());

@@ -230,8 +230,13 @@ int launch_color_lab_hist(cbv_ctx* ctx, const u8* src, u8* lab, u32* aux, Geom g
 // ---------------------------------------------------------------------------
 // CLAHE LUT: one workgroup (256 threads = 256 bins) per tile
 // ---------------------------------------------------------------------------
+// `packed` (may be null): per frame [tiles_y + 1 bands][tiles_x + 1 column pairs][256] words holding, for L value v,
+// the four LUT bytes k_clahe_apply interpolates between: byte 0 = (ty1, tx1), 1 = (ty1, tx2), 2 = (ty2, tx1),
+// 3 = (ty2, tx2), where band b has ty1 = clamp(b - 1), ty2 = clamp(b) and pair p has tx1 = clamp(p - 1),
+// tx2 = clamp(p).  A tile writes its byte into every word it is a corner of (one to nine of them), so the apply
+// kernel does ONE gather per pixel instead of four.
 __global__ __launch_bounds__(256) void k_clahe_lut(const u32* __restrict__ aux, u8* __restrict__ luts, ClaheGeom cg,
-                                                    int tiles_total)
+                                                    int tiles_total, u8* __restrict__ packed)
 {
     __shared__ int red[4];
     __shared__ int scan[256];
@@ -263,14 +268,33 @@ __global__ __launch_bounds__(256) void k_clahe_lut(const u32* __restrict__ aux, 
         __syncthreads();
     }
     float f = (float)scan[t] * cg.lut_scale;
-    luts[((size_t)blockIdx.y * tiles_total + tile) * 256 + t] = d_sat8_f(f);
+    const u8 lv = d_sat8_f(f);
+    luts[((size_t)blockIdx.y * tiles_total + tile) * 256 + t] = lv;
+    if (packed) {
+        const int tx = tile % cg.tiles_x, ty = tile / cg.tiles_x;
+        const int pairs = cg.tiles_x + 1, bands = cg.tiles_y + 1;
+        u8* pf = packed + (size_t)blockIdx.y * bands * pairs * 1024;
+        for (int b = ty; b <= ty + 1; b++) {
+            // tile row ty is ty2 of band ty and ty1 of band ty + 1; clamping adds ty1 of band 0 / ty2 of the last band
+            for (int yrole = 0; yrole < 2; yrole++) {
+                const int want = yrole == 0 ? min(max(b - 1, 0), cg.tiles_y - 1) : min(b, cg.tiles_y - 1);
+                if (want != ty) continue;
+                for (int p = tx; p <= tx + 1; p++)
+                    for (int xrole = 0; xrole < 2; xrole++) {
+                        const int wantx = xrole == 0 ? min(max(p - 1, 0), cg.tiles_x - 1) : min(p, cg.tiles_x - 1);
+                        if (wantx != tx) continue;
+                        pf[(((size_t)b * pairs + p) * 256 + t) * 4 + yrole * 2 + xrole] = lv;
+                    }
+            }
+        }
+    }
 }
 
-int launch_clahe_lut(cbv_ctx* ctx, const u32* aux, u8* luts, ClaheGeom cg, int batch)
+int launch_clahe_lut(cbv_ctx* ctx, const u32* aux, u8* luts, ClaheGeom cg, int batch, u32* packed)
 {
     int tiles = cg.tiles_x * cg.tiles_y;
     prof_begin(ctx, CBV_K_CLAHE_LUT);
-    hipLaunchKernelGGL(k_clahe_lut, dim3(tiles, batch), dim3(256), 0, ctx->stream, aux, luts, cg, tiles);
+    hipLaunchKernelGGL(k_clahe_lut, dim3(tiles, batch), dim3(256), 0, ctx->stream, aux, luts, cg, tiles, (u8*)packed);
     prof_end(ctx, CBV_K_CLAHE_LUT);
     CBV_HIP(ctx, hipGetLastError());
     return CBV_OK;
@@ -288,17 +312,16 @@ __device__ __forceinline__ int d_ab_to_xz(int i)
 }
 
 #define CLAHE_MAX_TILES_X 32
-__global__ __launch_bounds__(256) void k_clahe_apply(const u8* __restrict__ lab, const u8* __restrict__ luts,
+__global__ __launch_bounds__(256) void k_clahe_apply(const u8* __restrict__ lab, const u32* __restrict__ packed,
                                                       u8* __restrict__ dst, Geom g, ClaheGeom cg,
                                                       const StaticTabs* __restrict__ st, int rows_per_wg,
                                                       int tiles_total)
 {
     // static LDS: table addresses become ds_read immediates (no per-lookup base add)
     __shared__ u16 inv_gamma[INV_GAMMA_TAB_SIZE];
-    __shared__ u16 lab_yf[512];
+    __shared__ u32 lab_yf[256];          // y | ify << 16: one gather for the pair
     __shared__ int invc[16];
-    __shared__ u8 lut1[CLAHE_MAX_TILES_X * 256];
-    __shared__ u8 lut2[CLAHE_MAX_TILES_X * 256];
+    extern __shared__ __align__(16) u32 pk[]; // [tiles_x + 1][256]: this band's packed corner words (k_clahe_lut)
 
     // band b holds the rows whose unclamped ty1 is b - 1
     const int band = blockIdx.y;
@@ -318,14 +341,12 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const u8* __restrict__ lab,
     const int y0 = yb0 + blockIdx.x * rows_per_wg;
     if (y0 >= yb1) return;
     const int y1 = min(y0 + rows_per_wg, yb1);
-    const int ty1c = min(max(band - 1, 0), cg.tiles_y - 1), ty2c = min(band, cg.tiles_y - 1);
 
     lds_copy(inv_gamma, st->inv_gamma, INV_GAMMA_TAB_SIZE * 2);
-    lds_copy(lab_yf, st->lab_yf, 1024);
+    lds_copy(lab_yf, st->lab_yf, 1024); // u16 pairs (y, ify) read back as one word
     if (threadIdx.x < 9) invc[threadIdx.x] = st->inv[threadIdx.x];
-    const u8* lf = luts + (size_t)blockIdx.z * tiles_total * 256;
-    lds_copy(lut1, lf + (size_t)ty1c * cg.tiles_x * 256, cg.tiles_x * 256);
-    lds_copy(lut2, lf + (size_t)ty2c * cg.tiles_x * 256, cg.tiles_x * 256);
+    const int pairs = cg.tiles_x + 1;
+    lds_copy(pk, packed + ((size_t)blockIdx.z * (cg.tiles_y + 1) + band) * pairs * 256, pairs * 1024);
     __syncthreads();
 
     const size_t fo = (size_t)blockIdx.z * g.frame_stride;
@@ -341,7 +362,7 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const u8* __restrict__ lab,
         const int x0 = gi * 4;
         const int npx = min(4, g.w - x0);
         const bool fast = aligned && npx == 4;
-        int o1[4], o2[4];
+        int op[4]; // byte offset of the pixel's column pair in pk
         float xa[4], xa1[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -349,8 +370,7 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const u8* __restrict__ lab,
             int tx1 = d_floor_f(txf);
             xa[k] = txf - (float)tx1;
             xa1[k] = 1.0f - xa[k];
-            o2[k] = min(tx1 + 1, cg.tiles_x - 1) * 256;
-            o1[k] = max(tx1, 0) * 256;
+            op[k] = min(max(tx1 + 1, 0), cg.tiles_x) * 1024;
         }
         for (int y = y0; y < y1; y++) {
             const float tyf = (float)y * inv_th - 0.5f;
@@ -373,13 +393,15 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const u8* __restrict__ lab,
             for (int k = 0; k < 4; k++) {
                 if (k < npx) {
                     const int v = px_get(px, 3 * k);
-                    float ra = (float)lut1[o1[k] + v] * xa1[k] + (float)lut1[o2[k] + v] * xa[k];
-                    float rb = (float)lut2[o1[k] + v] * xa1[k] + (float)lut2[o2[k] + v] * xa[k];
+                    const u32 cw = *(const u32*)((const u8*)pk + op[k] + v * 4); // the four corner LUT values of L = v
+                    float ra = (float)(cw & 255u) * xa1[k] + (float)((cw >> 8) & 255u) * xa[k];
+                    float rb = (float)((cw >> 16) & 255u) * xa1[k] + (float)(cw >> 24) * xa[k];
                     float res = ra * ya1 + rb * ya;
                     const int LL = (int)__builtin_amdgcn_cvt_pk_u8_f32(res, 0, 0u); // round-half-even + saturate
                     // Lab2RGBinteger
                     const int aa = px_get(px, 3 * k + 1), bb = px_get(px, 3 * k + 2);
-                    const int yv = lab_yf[LL * 2], ify = lab_yf[LL * 2 + 1];
+                    const u32 yf = lab_yf[LL];
+                    const int yv = (int)(yf & 0xFFFFu), ify = (int)(yf >> 16);
                     const int adiv = ((5 * aa * 53687 + (1 << 7)) >> 13) - 128 * LAB_BASE / 500;
                     const int bdiv = ((bb * 41943 + (1 << 4)) >> 9) - 128 * LAB_BASE / 200 + 1;
                     const int xv = d_ab_to_xz(ify + adiv), zv = d_ab_to_xz(ify - bdiv);
@@ -413,7 +435,7 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const u8* __restrict__ lab,
     }
 }
 
-int launch_clahe_apply(cbv_ctx* ctx, const u8* lab, const u8* luts, u8* dst, Geom g, ClaheGeom cg, int batch)
+int launch_clahe_apply(cbv_ctx* ctx, const u8* lab, const u32* packed, u8* dst, Geom g, ClaheGeom cg, int batch)
 {
     const int rows_per_wg = 8;
     int tiles = cg.tiles_x * cg.tiles_y;
@@ -421,8 +443,8 @@ int launch_clahe_apply(cbv_ctx* ctx, const u8* lab, const u8* luts, u8* dst, Geo
     // a band is at most th rows (+1 for rounding)
     dim3 grid((cg.th + 1 + rows_per_wg - 1) / rows_per_wg, cg.tiles_y + 1, batch);
     prof_begin(ctx, CBV_K_CLAHE_APPLY);
-    hipLaunchKernelGGL(k_clahe_apply, grid, dim3(256), 0, ctx->stream, lab, luts, dst, g, cg, ctx->tabs, rows_per_wg,
-                       tiles);
+    hipLaunchKernelGGL(k_clahe_apply, grid, dim3(256), (size_t)(cg.tiles_x + 1) * 1024, ctx->stream, lab, packed, dst, g, cg, ctx->tabs,
+                       rows_per_wg, tiles);
     prof_end(ctx, CBV_K_CLAHE_APPLY);
     CBV_HIP(ctx, hipGetLastError());
     return CBV_OK;

@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# The CPU oracle is OpenMP code; a GPU box can show hundreds of CPUs in its affinity mask while its CPU share lets
+# only a handful run (a team of that size thrashes: the same suite took 20 s on one box and 190 s on another).
+os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
