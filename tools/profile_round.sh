@@ -1,12 +1,12 @@
 #!/bin/bash
 # Round profile: kernel durations (rocprofv3 --kernel-trace --stats) and HBM traffic (separate --pmc passes).
 # Writes under gpurun_out/prof_<tag>; copy what should be judged into profiles/.
-tag=${1:-r01}
+tag=${1:-r02}
 out=$PWD/gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
 python bench.py > $out/bench.json 2> $out/bench.err || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o run -- python3 bench.py --steps 3 --warmup 1 > $out/bench_under_rocprof.json 2> $out/rocprof_stats.err || exit 2
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o run -- python3 bench.py --steps 3 --warmup 1 --cpu-frames 0 > $out/bench_under_rocprof.json 2> $out/rocprof_stats.err || exit 2
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_timed -o run -- python3 bench.py --steps 3 --warmup 1 --no-profile-pass --cpu-frames 0 > $out/bench_timed_only_under_rocprof.json 2> $out/rocprof_stats_timed.err || exit 2
 find $out/stats_timed -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/kernel_stats_timed_only.csv
 rm -rf $out/stats_timed
