@@ -90,6 +90,36 @@ __global__ __launch_bounds__(1024) void k(float* out, float seed, unsigned useed
     out[blockIdx.x * blockDim.x + threadIdx.x] = s + (float)u;
 }
 
+// packed f32 (64-bit register pairs): 8 independent pair chains per lane
+typedef float f2v __attribute__((ext_vector_type(2)));
+template <int OP>
+__global__ __launch_bounds__(1024) void k_pk(float* out, float seed)
+{
+    f2v acc[8], w[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        acc[i] = f2v{seed + threadIdx.x * 0.001f + i, seed - i};
+        w[i] = f2v{1.0001f + i * 1e-6f, 0.9999f};
+    }
+    f2v x = {0.5f, 0.25f};
+    for (int it = 0; it < N_IT; it++) {
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                if (OP == 0) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(w[i]), "v"(x));
+                if (OP == 1) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc[i]) : "v"(w[(i + 3) & 7]), "v"(x));
+                if (OP == 2) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(acc[i]) : "v"(w[i]));
+                if (OP == 3) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(acc[i]) : "v"(w[i]));
+                if (OP == 4) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc[i]) : "v"(w[(i + 3) & 7]), "v"(x));
+            }
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) s += acc[i].x + acc[i].y;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 // LDS read throughput: every lane reads its own bank (conflict-free), 8 reads in flight
 template <int BYTES>
 __global__ __launch_bounds__(1024) void k_lds(float* out)
@@ -152,6 +182,16 @@ int main()
     }
     OPS(X)
 #undef X
+#define PK(id, name)                                                                                         \
+    {                                                                                                         \
+        const float ms = time_ms([&] { hipLaunchKernelGGL(k_pk<id>, dim3(256), dim3(1024), 0, 0, d, 1.f); }); \
+        printf("%-30s %9.3f %9.2f  (two results per instruction)\n", name, ms, ms * 1e6 / (4.0 * N_IT * 16) * 2.4); \
+    }
+    PK(0, "v_pk_fma_f32")
+    PK(1, "v_pk_fma_f32 op_sel hi,hi")
+    PK(4, "v_pk_fma_f32 op_sel lo,lo")
+    PK(2, "v_pk_add_f32")
+    PK(3, "v_pk_mul_f32")
     {
         const float ms = time_ms([&] { hipLaunchKernelGGL(k_lds<4>, dim3(256), dim3(1024), 0, 0, d); });
         printf("%-30s %9.3f %9.2f  (clk per wave-instr per CU: 16 waves share one LDS)\n", "ds_read_b32 conflict-free", ms, ms * 1e6 / (16.0 * N_IT * 8) * 2.4);
