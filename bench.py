@@ -164,7 +164,7 @@ def main():
     ap.add_argument("--cpu-frames-1t", type=int, default=24, help="frames of the 1-thread CPU baseline sample")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--no-4k", action="store_true", help="skip the configs[3] (3840x2160) leg")
-    ap.add_argument("--splits", type=int, default=4, help="a step's frames are enqueued as this many consecutive runs "
+    ap.add_argument("--splits", type=int, default=2, help="a step's frames are enqueued as this many consecutive runs "
                     "(the temporal scan of one run overlaps the enhancement of the next)")
     args = ap.parse_args()
     if args.gpus < 1:
