@@ -386,11 +386,11 @@ def main():
                 pass
         valu_ach = valu_ops_px * w * h * frames_per_launch / (avg_ms * 1e-3) / 1e12 if bl_n else float("nan")
         valu_peak = 256 * 4 * 32 * 2.4e9 / 1e12
-        # issue-clock model from measured per-instruction costs (tools/ubench_pk.hip, clocks per wave64 instruction per
-        # SIMD at 2.4 GHz): per tap and output v_sad_u8 4.62 + v_lshlrev 3.2 + 3 v_fma 9.0 + v_add 2.53
-        # + 0.92 v_cvt_f32_ubyte 4.58; the other (counted - modelled) ops per pixel at ~3
-        per_tap = 4.62 + 3.2 + 9.0 + 2.53 + 0.92 * 4.58
-        issue_clk_px_wave = 49 * per_tap + max(0.0, valu_ops_px - 49 * 6.92) * 3.0
+        # issue-clock model from measured per-instruction costs (tools/ubench_ops.hip -> profiles/r02/issue_costs.txt, clocks
+        # per wave64 instruction per SIMD at 2.4 GHz, 4 waves/SIMD): per tap and output v_sad_u8 4.63 + v_lshlrev 4.41 +
+        # 3 v_fma 10.02 + v_add 3.18 + 0.92 v_cvt_f32_ubyte 4.70; the other (counted - modelled) ops per pixel at ~3.5
+        per_tap = 4.63 + 4.41 + 10.02 + 3.18 + 0.92 * 4.70
+        issue_clk_px_wave = 49 * per_tap + max(0.0, valu_ops_px - 49 * 6.92) * 3.5
         issue_bound_ms = issue_clk_px_wave * (w * h * frames_per_launch / 64.0) / (256 * 4) / 2.4e9 * 1e3
         out = {
             "metric": "frames/sec enhance->warp->64-sq detect @1080p; % HBM roofline",
@@ -414,7 +414,7 @@ def main():
                                   "issue_bound_ms_per_launch": round(issue_bound_ms, 4),
                                   "issue_frac_live": round(issue_bound_ms / avg_ms, 4) if bl_n else None,
                                   "issue_frac_alone": round(issue_bound_ms / kernels["k_bilateral"]["avg_ms"], 4) if "k_bilateral" in kernels else None,
-                                  "issue_note": "time the kernel's own instruction mix needs at the measured issue cost of each instruction (tools/ubench_pk.hip) / time taken, live in the timed region (other kernels share the CUs) and alone (single-lane pass)"}},
+                                  "issue_note": "time the kernel's own instruction mix needs at the measured issue cost of each instruction (profiles/r02/issue_costs.txt) / time taken, live in the timed region (other kernels share the CUs) and alone (single-lane pass; the 768-lane workgroups trade 11 % of the kernel's own speed for co-residency with the other lane)"}},
             "path_roofline": {"alg_bytes_per_frame": path_bytes, "achieved": round(path_bytes * fps / world / 1e9, 2), "peak": HBM_PEAK_GBPS,
                               "unit": "GB/s", "frac": round(path_bytes * fps / world / 1e9 / HBM_PEAK_GBPS, 5),
                               "note": "SURVEY 8(d) algorithmic bytes (enhance = 10 N) although the timed path never materialises process_pipeline's "
