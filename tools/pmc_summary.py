@@ -20,7 +20,8 @@ def load(path):
         d["_grid"] = int(r["Grid_Size"])
     best = {}
     for (k, _), d in rows.items():
-        if k not in best or d["_grid"] > best[k]["_grid"] or (d["_grid"] == best[k]["_grid"] and d["_dur"] < best[k]["_dur"]):
+        # the batched launch: largest grid, and among equal grids (persistent kernels) the longest one
+        if k not in best or d["_grid"] > best[k]["_grid"] or (d["_grid"] == best[k]["_grid"] and d["_dur"] > best[k]["_dur"]):
             best[k] = d
     return best
 
