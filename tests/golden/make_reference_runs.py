@@ -46,8 +46,12 @@ sys.path.insert(0, REF)
 
 from tests.golden import cv2_oracle_shim as shim  # noqa: E402
 
-assert "cv2" not in sys.modules, "a real cv2 is importable: record against it instead of the shim"
-sys.modules["cv2"] = shim.as_module()
+try:  # a machine with opencv-python records REAL OpenCV numbers; this image has none (no network, nothing installed)
+    import cv2 as _cv2_real
+    CV2_KIND = "opencv-python " + _cv2_real.__version__
+except ImportError:
+    sys.modules["cv2"] = shim.as_module()
+    CV2_KIND = "oracle shim (tests/golden/cv2_oracle_shim.py): OpenCV-side numbers are the oracle's own"
 
 # the reference reads color_profile.json / piece_detector_settings.json from the cwd at construction
 # (frame_enhancer.py:48, piece_detector.py:54): run inside a scratch directory holding copies of the shipped files
@@ -132,7 +136,7 @@ def small_frames():
 
 
 def gold_enhancer():
-    arrs, meta = {}, {"import_log": IMPORT_LOG.strip().splitlines(), "profiles": PROFILES, "calls": {}}
+    arrs, meta = {}, {"cv2": CV2_KIND, "import_log": IMPORT_LOG.strip().splitlines(), "profiles": PROFILES, "calls": {}}
     enh = quiet(frame_enhancer.ImageEnhancer)
     assert type(enh).__name__ == "ImageEnhancerPython"       # the selector fell back as frame_enhancer.py:19-21 says
     assert enh.profile == PROFILES["shipped"]                 # read from cwd
