@@ -20,6 +20,8 @@ their outputs are written as data files under tests/golden/:
                                classify_hand_pattern, focus squares                          (change_detector.py:36-201)
   ref_change_planes.npz        a few mean / variance planes of that run (all planes are covered by sha256)
   ref_refine_grid.json         SmartGridExtractor.refine_grid                                (grid_extractor.py:66-121)
+  ref_cython_twins.json        ImageEnhancerCython / ChangeDetectorCython (src/cython/*.pyx, built by
+                               oracle/build_ref_cython.sh into oracle/_ref/) on the same inputs: identical or not
 
 What these pin: see cv2_oracle_shim.py — the reference's numpy arithmetic and control flow exactly; the OpenCV-side
 pixel numbers are the oracle's own (circular) and stay "parity unpinned".
@@ -468,6 +470,93 @@ def gold_change_sequence():
     np.savez_compressed(os.path.join(OUT, "ref_change_planes.npz"), **planes)
 
 
+def gold_cython_twins():
+    """The reference's Cython twins (src/cython/*.pyx: the slot its selector fills first, frame_enhancer.py:12-21),
+    compiled by oracle/build_ref_cython.sh into oracle/_ref/, driven on the same inputs as the Python classes above.
+    Records whether every output is identical; the HIP classes are compared with the Python classes' fixtures, so
+    this is what makes those fixtures speak for the Cython twins too."""
+    ref_dir = os.path.join(ROOT, "oracle", "_ref")
+    out = {"built": False}
+    if not os.path.isdir(os.path.join(ref_dir, "src", "cython")):
+        with open(os.path.join(OUT, "ref_cython_twins.json"), "w") as f:
+            json.dump(out, f)
+        return
+    sys.path.insert(0, ref_dir)
+    with contextlib.redirect_stdout(io.StringIO()):
+        from src.cython.frame_enhancer_cython import ImageEnhancerCython
+        from src.cython.change_detector_cython import ChangeDetectorCython
+    out["built"] = True
+    # ImageEnhancerCython vs the recorded ImageEnhancerPython outputs
+    fx = np.load(os.path.join(OUT, "ref_enhancer.npz"))
+    enh = quiet(ImageEnhancerCython)
+    assert enh.profile == PROFILES["shipped"]
+    n = same = 0
+    diffs = []
+    def chk(name, got):
+        nonlocal n, same
+        n += 1
+        if np.array_equal(got, fx[name]):
+            same += 1
+        else:
+            diffs.append([name, int(np.abs(got.astype(np.int16) - fx[name].astype(np.int16)).max())])
+    for fname in ("smooth", "noise", "sweep", "scene_dim", "odd"):
+        for pname, prof in PROFILES.items():
+            enh.profile = prof
+            chk("profile_%s_%s" % (pname, fname), enh.apply_color_profile(fx["in_" + fname]))
+    for fname in ("smooth", "scene_dim", "odd"):
+        f = fx["in_" + fname]
+        chk("lighting_" + fname, enh.correct_lighting(f))
+        chk("noise_" + fname, enh.reduce_noise(f))
+        chk("sharpen_" + fname, enh.sharpen(f))
+        chk("normalize_" + fname, enh.normalize_intensity(f))
+        g, b = enh.prepare_analysis(f)
+        chk("gray_" + fname, g)
+        chk("binary_" + fname, b)
+        for pname in ("shipped", "radical", "none"):
+            enh.profile = PROFILES[pname] if pname != "none" else {}
+            chk("pipeline_%s_%s" % (pname, fname), enh.process_pipeline(f))
+    out["frame_enhancer"] = {"outputs": n, "identical": same, "differences": diffs,
+                             "sharpen_kernel_dtype": str(np.asarray(enh.sharpen_kernel).dtype)}
+    # ChangeDetectorCython vs the recorded ChangeDetectorPython runs
+    rec = json.load(open(os.path.join(OUT, "ref_change_sequence.json")))
+    pts = S.scaled_corners(W, H)
+    cd_report = []
+    for run in rec["runs"]:
+        cd = quiet(ChangeDetectorCython)
+        ge = grid_extractor.GridExtractor()
+        frames_same = 0
+        first_diff = None
+        for fr in run["frames"]:
+            i = fr["i"]
+            for k, v in run["attrs"].items():
+                setattr(cd, k, v)
+            img = oracle_frame(W, H, run["scene"], stream_id=run["stream_id"], frame_idx=i, frames_per_ply=run["frames_per_ply"])
+            squares = ge.split_board(board_detection.warp_image(img, pts)[0])
+            if fr.get("calibrated"):
+                cd.calibrate(squares)
+            if fr.get("focus_set"):
+                cd.set_focus_squares([tuple(p) for p in run["focus"]])
+            if fr.get("focus_cleared"):
+                cd.clear_focus()
+            detailed = cd.detect_changes_detailed(squares) if cd.is_calibrated else {}
+            got = plain([[p[0], p[1], v["z_score"], v["pct_changed"], v["intensity"], bool(v["is_circular"]), v["center_ratio"]]
+                         for p, v in detailed.items()])
+            if fr.get("ema"):
+                cd.update_all_references(squares)
+            ok = got == fr["detailed"]
+            if cd.is_calibrated:
+                keys = sorted(cd.means.keys())
+                ok = ok and sha(np.concatenate([cd.means[k].ravel() for k in keys])) == fr["means_sha256"] \
+                    and sha(np.concatenate([cd.variances[k].ravel() for k in keys])) == fr["vars_sha256"]
+            frames_same += ok
+            if not ok and first_diff is None:
+                first_diff = i
+        cd_report.append({"run": run["name"], "frames": len(run["frames"]), "identical": frames_same, "first_difference": first_diff})
+    out["change_detector"] = cd_report
+    with open(os.path.join(OUT, "ref_cython_twins.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 def gold_refine_grid():
     out = []
     pts = S.scaled_corners(W, H)
@@ -491,5 +580,6 @@ if __name__ == "__main__":
     gold_chain_sequence()
     gold_change_sequence()
     gold_refine_grid()
+    gold_cython_twins()
     shutil.rmtree(_SCRATCH, ignore_errors=True)
     print("reference-run fixtures written to", OUT)

@@ -261,3 +261,16 @@ def test_composed_chain_is_the_references(oracle, run_idx):
         assert R.result_rows(results) == rec["results"], rec["i"]
         assert R.bits(visual) == rec["visual_bits"] and R.detector_state(det) == rec["state"], rec["i"]
         assert R.bits(p for p, r in results.items() if r["has_piece"]) == rec["occupied_bits"]
+
+
+def test_cython_twins_agree_with_the_python_classes():
+    """The reference's selector prefers its Cython twins when they are built (frame_enhancer.py:12-21,
+    change_detector.py:11-19).  They were compiled from the reference's own sources (oracle/build_ref_cython.sh ->
+    oracle/_ref/) and driven on the same inputs when the fixtures were recorded: every output identical, so the
+    fixtures above are the twins' outputs as well."""
+    rep = R.load_json("ref_cython_twins.json")
+    assert rep["built"]
+    fe = rep["frame_enhancer"]
+    assert fe["outputs"] == fe["identical"] == 57 and fe["differences"] == [] and fe["sharpen_kernel_dtype"] == "float32"
+    for run in rep["change_detector"]:
+        assert run["frames"] == run["identical"] and run["first_difference"] is None, run
