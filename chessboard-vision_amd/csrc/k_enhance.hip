@@ -597,6 +597,14 @@ __device__ unsigned int g_sh_count;
 #define SH_STAMP(k) do { } while (0)
 #endif
 
+typedef unsigned short shb_u2 __attribute__((ext_vector_type(2)));
+typedef short shb_s2 __attribute__((ext_vector_type(2)));
+
+// PACKED: the same arithmetic in packed 16-bit integers, two bytes per instruction, for kernels whose intermediate
+// a * box + (c - a) * centre stays inside int16 (|a| * 2295 + |c - a| * 255 <= 32767; the reference's -1 / 9 kernel
+// gives [-2295, 2550]).  Exact either way: the float form only ever holds small integers.  About 7 vector
+// instructions per output byte instead of 20 (profiles/r02/sq_counters.txt).
+template <bool PACKED>
 __global__ __launch_bounds__(256) void k_sharpen_box(const u8* __restrict__ src, u8* __restrict__ dst,
                                                       u32* __restrict__ aux, int tiles_total, Geom g, float a, float ca,
                                                       int tiles_xn, int tiles_n)
@@ -663,7 +671,78 @@ __global__ __launch_bounds__(256) void k_sharpen_box(const u8* __restrict__ src,
     const int lc = threadIdx.x & 63, rq = threadIdx.x >> 6; // 64 chunks of 16 B x 4 row quads
     const int x0 = xb0 + lc * 16;
     int imin = 255, imax = 0;
-    if (x0 < wb) {
+    if (PACKED && x0 < wb) {
+        const int nbytes = min(16, wb - x0);
+        // the kernel's two integers in every 16-bit lane
+        const int ai = (int)a, cai = (int)ca;
+        const shb_s2 A2 = {(short)ai, (short)ai};
+        const shb_u2 C2 = {(unsigned short)cai, (unsigned short)cai};
+        shb_u2 h[3][8];  // horizontal 3-sums of the last three staged rows, output bytes (2m, 2m + 1) in one register
+        shb_u2 cc[2][8]; // centre bytes of the last two staged rows
+        shb_s2 vmin = {32767, 32767}, vmax = {-32768, -32768};
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            const int ly = rq * 4 + r; // staged row index (tile row 0 = y0 - 1)
+            const u8* tr = &tile[ly * SHB_PITCH + 16 + lc * 16];
+            u32 d[6];
+            d[0] = *(const u32*)(tr - 4);
+            const uint4 m = *(const uint4*)tr;
+            d[1] = m.x;
+            d[2] = m.y;
+            d[3] = m.z;
+            d[4] = m.w;
+            d[5] = *(const u32*)(tr + 16);
+            // window element k (byte x0 - 3 + k) is byte k + 1 of d[].  P[p] = elements (2p, 2p + 1), Q[p] = elements
+            // (2p + 1, 2p + 2), zero-extended to 16 bits by ONE v_perm_b32 each
+            auto pair_at = [&](int e) { // elements (e, e + 1) -> bytes (e + 1, e + 2) of d
+                const int b0 = e + 1, b1 = e + 2;
+                const int w0 = b0 >> 2, w1 = b1 >> 2;
+                // selector bytes: result byte 0 = first element, byte 2 = second element, bytes 1 and 3 = 0
+                const u32 sel = (u32)((b0 & 3) | (w0 == w1 ? 0 : 0)) | (0x0cu << 8) | ((u32)(((b1 & 3) + (w1 != w0 ? 4 : 0))) << 16) | (0x0cu << 24);
+                return __builtin_bit_cast(shb_u2, __builtin_amdgcn_perm(d[w1], d[w0], sel));
+            };
+#pragma unroll
+            for (int m2 = 0; m2 < 8; m2++) {
+                const int t = 2 * m2; // output bytes (t, t + 1): window elements t, t + 3, t + 6
+                const shb_u2 left = pair_at(t), mid = pair_at(t + 3), right = pair_at(t + 6);
+                h[r % 3][m2] = (left + mid) + right;
+                cc[r & 1][m2] = mid;
+            }
+            if (r >= 2) {
+                const int yo = y0 + ly - 2; // centre row of the three last staged rows
+                if (yo < g.h) {
+                    u32 o[4];
+#pragma unroll
+                    for (int m2 = 0; m2 < 8; m2++) {
+                        const shb_u2 S = (h[0][m2] + h[1][m2]) + h[2][m2];
+                        const shb_u2 t2 = cc[(r - 1) & 1][m2] * C2;
+                        const shb_s2 v = __builtin_bit_cast(shb_s2, S) * A2 + __builtin_bit_cast(shb_s2, t2);
+                        u32 pk;
+                        asm("v_sat_pk_u8_i16 %0, %1" : "=v"(pk) : "v"(v)); // clamp both lanes to [0, 255], bytes 0 and 1
+                        if (m2 & 1) o[m2 >> 1] |= pk << 16;
+                        else o[m2 >> 1] = pk & 0xFFFFu;
+                        if (nbytes == 16 || 2 * m2 + 1 < nbytes) {
+                            vmin = __builtin_elementwise_min(vmin, v);
+                            vmax = __builtin_elementwise_max(vmax, v);
+                        } else if (2 * m2 < nbytes) { // odd tail: only the first lane is an output byte
+                            vmin.x = min(vmin.x, v.x);
+                            vmax.x = max(vmax.x, v.x);
+                        }
+                    }
+                    u8* q = df + (size_t)yo * g.stride + x0;
+                    if (nbytes == 16 && al16) *(uint4*)q = make_uint4(o[0], o[1], o[2], o[3]);
+                    else
+                        for (int k = 0; k < nbytes; k++) q[k] = (u8)(o[k >> 2] >> ((k & 3) * 8));
+                }
+            }
+        }
+        // min / max of the SATURATED outputs = the clamped min / max of the unsaturated values
+        if (vmin.x <= vmax.x || vmin.y <= vmax.y) {
+            imin = min(max((int)min(vmin.x, vmin.y), 0), 255);
+            imax = min(max((int)max(vmax.x, vmax.y), 0), 255);
+        }
+    }
+    if (!PACKED && x0 < wb) {
         const int nbytes = min(16, wb - x0);
         float h[3][16]; // horizontal 3-sums of the last three staged rows
         float c[2][16]; // centre values of the last two staged rows
@@ -776,8 +855,13 @@ int launch_sharpen(cbv_ctx* ctx, const u8* src, u8* dst, u32* aux, int tiles, Ge
     prof_begin(ctx, CBV_K_SHARPEN);
     if (box) {
         const int txn = (g.w * 3 + SHB_TB - 1) / SHB_TB, tyn = (g.h + SHB_TH - 1) / SHB_TH;
-        hipLaunchKernelGGL(k_sharpen_box, dim3(txn * tyn, 1, batch), dim3(256), 0, ctx->stream, src, dst, aux, tiles, g, a, c - a,
-                           txn, txn * tyn);
+        const bool packed = fabsf(a) * 2295.f + fabsf(c - a) * 255.f <= 32767.f && (c - a) >= 0.f; // centre weight as u16
+        if (packed)
+            hipLaunchKernelGGL(k_sharpen_box<true>, dim3(txn * tyn, 1, batch), dim3(256), 0, ctx->stream, src, dst, aux, tiles, g, a,
+                               c - a, txn, txn * tyn);
+        else
+            hipLaunchKernelGGL(k_sharpen_box<false>, dim3(txn * tyn, 1, batch), dim3(256), 0, ctx->stream, src, dst, aux, tiles, g, a,
+                               c - a, txn, txn * tyn);
     } else {
         int txn = (g.w + SH_TW - 1) / SH_TW, tyn = (g.h + SH_TH - 1) / SH_TH;
         hipLaunchKernelGGL(k_sharpen, dim3(txn * tyn, 1, batch), dim3(256), 0, ctx->stream, src, dst, aux, tiles, g, k[0],
