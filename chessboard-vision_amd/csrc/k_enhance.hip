@@ -673,6 +673,7 @@ __global__ __launch_bounds__(256) void k_sharpen_box(const u8* __restrict__ src,
     int imin = 255, imax = 0;
     if (PACKED && x0 < wb) {
         const int nbytes = min(16, wb - x0);
+        const bool full = nbytes == 16;
         // the kernel's two integers in every 16-bit lane
         const int ai = (int)a, cai = (int)ca;
         const shb_s2 A2 = {(short)ai, (short)ai};
@@ -721,23 +722,28 @@ __global__ __launch_bounds__(256) void k_sharpen_box(const u8* __restrict__ src,
                         asm("v_sat_pk_u8_i16 %0, %1" : "=v"(pk) : "v"(v)); // clamp both lanes to [0, 255], bytes 0 and 1
                         if (m2 & 1) o[m2 >> 1] |= pk << 16;
                         else o[m2 >> 1] = pk & 0xFFFFu;
-                        if (nbytes == 16 || 2 * m2 + 1 < nbytes) {
+                        if (full) { // all 16 bytes are outputs (every chunk but the row's last): no per-byte masks
                             vmin = __builtin_elementwise_min(vmin, v);
                             vmax = __builtin_elementwise_max(vmax, v);
-                        } else if (2 * m2 < nbytes) { // odd tail: only the first lane is an output byte
-                            vmin.x = min(vmin.x, v.x);
-                            vmax.x = max(vmax.x, v.x);
                         }
                     }
                     u8* q = df + (size_t)yo * g.stride + x0;
-                    if (nbytes == 16 && al16) *(uint4*)q = make_uint4(o[0], o[1], o[2], o[3]);
-                    else
-                        for (int k = 0; k < nbytes; k++) q[k] = (u8)(o[k >> 2] >> ((k & 3) * 8));
+                    if (full && al16) *(uint4*)q = make_uint4(o[0], o[1], o[2], o[3]);
+                    else {
+                        for (int k = 0; k < nbytes; k++) {
+                            const int bv = (int)((o[k >> 2] >> ((k & 3) * 8)) & 255u);
+                            q[k] = (u8)bv;
+                            if (!full) {
+                                imin = min(imin, bv);
+                                imax = max(imax, bv);
+                            }
+                        }
+                    }
                 }
             }
         }
         // min / max of the SATURATED outputs = the clamped min / max of the unsaturated values
-        if (vmin.x <= vmax.x || vmin.y <= vmax.y) {
+        if (full && vmin.x <= vmax.x) {
             imin = min(max((int)min(vmin.x, vmin.y), 0), 255);
             imax = min(max((int)max(vmax.x, vmax.y), 0), 255);
         }
