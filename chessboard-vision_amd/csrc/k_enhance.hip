@@ -645,11 +645,33 @@ __global__ __launch_bounds__(256) void k_sharpen_box(const u8* __restrict__ src,
     for (int k = 0; k < SHB_VPT; k++) {
         const int i = threadIdx.x + k * 256;
         if (i >= SHB_NV) continue;
-        uint4 v = stg[k];
-        if (!plain[k]) {
-            const int r = i / SHB_VPR, c = i - r * SHB_VPR;
+        // vectors that are not whole inside the row are zero here; the few that straddle a row end are filled below
+        *(uint4*)&tile[i * 16] = plain[k] ? stg[k] : make_uint4(0, 0, 0, 0); // i = r * SHB_VPR + c and SHB_PITCH = 16 * SHB_VPR
+    }
+    // Row ends (REFLECT_101 on pixels, channel kept): at most three vectors per staged row hold bytes within one pixel
+    // of the row without lying whole inside it.  They get their own pass, one lane per vector, so the byte loop runs in
+    // ONE wave of an edge tile; inside the loop above it ran, one lane active, in nearly every wave of such a tile (the
+    // straddling vectors sit 66 lanes apart) and made up half of the kernel's vector instructions.
+    if (!al16 || xb0 == 0 || xb0 + SHB_TB + 16 > wb) { // workgroup-uniform: the tile touches a row end (or rows are unaligned)
+        __syncthreads(); // the zero fill above
+        const int nspecial = al16 ? (SHB_TH + 2) * 3 : SHB_NV; // unaligned rows: every vector takes the byte path
+        for (int t = threadIdx.x; t < nspecial; t += 256) {
+            int r, c;
+            if (al16) {
+                r = t / 3;
+                const int side = t - r * 3;
+                // side 0: the vector holding bytes -3 .. -1 (c = 0, first tile only); sides 1, 2: the vector holding
+                // byte wb and the one after it (bytes wb .. wb + 2 may spill into it)
+                c = side == 0 ? 0 : (wb - (xb0 - 16)) / 16 + (side - 1);
+                if (side == 0 && xb0 != 0) continue;
+                if (c < 0 || c >= SHB_VPR) continue;
+            } else {
+                r = t / SHB_VPR;
+                c = t - r * SHB_VPR;
+            }
             const int sy = d_reflect101(y0 - 1 + r, g.h);
             const int bs = xb0 - 16 + c * 16;
+            if (al16 && bs >= 0 && bs + 16 <= wb) continue; // whole inside: already staged
             u32 w4[4] = {0, 0, 0, 0};
             if (bs + 16 > -3 && bs < wb + 3) { // only bytes within one pixel of the row are ever used
                 for (int kk = 0; kk < 16; kk++) {
@@ -660,9 +682,8 @@ __global__ __launch_bounds__(256) void k_sharpen_box(const u8* __restrict__ src,
                     if (pxl >= -1 && pxl <= g.w) w4[kk >> 2] |= (u32)sf[(size_t)sy * g.stride + d_reflect101(pxl, g.w) * 3 + ch] << ((kk & 3) * 8);
                 }
             }
-            v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+            *(uint4*)&tile[(r * SHB_VPR + c) * 16] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
         }
-        *(uint4*)&tile[i * 16] = v; // i = r * SHB_VPR + c and SHB_PITCH = 16 * SHB_VPR
     }
     SH_STAMP(1);
     __syncthreads();
@@ -673,7 +694,9 @@ __global__ __launch_bounds__(256) void k_sharpen_box(const u8* __restrict__ src,
     int imin = 255, imax = 0;
     if (PACKED && x0 < wb) {
         const int nbytes = min(16, wb - x0);
-        const bool full = nbytes == 16;
+        // wave-uniform (a scalar branch, not per-lane selects): every lane of the wave owns 16 output bytes; false only
+        // for the wave that holds the row's last chunk
+        const bool full = __builtin_amdgcn_ballot_w64(nbytes != 16) == 0;
         // the kernel's two integers in every 16-bit lane
         const int ai = (int)a, cai = (int)ca;
         const shb_s2 A2 = {(short)ai, (short)ai};
@@ -720,8 +743,8 @@ __global__ __launch_bounds__(256) void k_sharpen_box(const u8* __restrict__ src,
                         const shb_s2 v = __builtin_bit_cast(shb_s2, S) * A2 + __builtin_bit_cast(shb_s2, t2);
                         u32 pk;
                         asm("v_sat_pk_u8_i16 %0, %1" : "=v"(pk) : "v"(v)); // clamp both lanes to [0, 255], bytes 0 and 1
-                        if (m2 & 1) o[m2 >> 1] |= pk << 16;
-                        else o[m2 >> 1] = pk & 0xFFFFu;
+                        if (m2 & 1) o[m2 >> 1] = __builtin_amdgcn_perm(pk, o[m2 >> 1], 0x05040100u); // bytes: lo.0 lo.1 hi.0 hi.1
+                        else o[m2 >> 1] = pk;
                         if (full) { // all 16 bytes are outputs (every chunk but the row's last): no per-byte masks
                             vmin = __builtin_elementwise_min(vmin, v);
                             vmax = __builtin_elementwise_max(vmax, v);
