@@ -619,3 +619,33 @@ def test_calls_from_several_threads_share_one_context_safely(gpu_ctx, oracle):
     for t in ts:
         t.join()
     assert not errs, errs
+
+
+def test_sharpen_every_row_end_residue(gpu_ctx, oracle):
+    """The packed sharpen stages rows as 16-byte vectors and fills the (up to three) vectors that straddle a row end in
+    a pass of their own: every residue of 3W mod 16, widths below one vector, rows that are 16-byte aligned (fast
+    staging) and rows that are not (byte staging), heights around the 16-row tile, and kernels on both sides of the
+    int16 range that selects the packed arithmetic."""
+    from chessboard_vision_amd.frame_enhancer import ImageEnhancer
+    e = ImageEnhancer()
+    rng = np.random.default_rng(42)
+    widths = list(range(1, 23)) + [336, 337, 341, 342, 343, 346, 347, 348, 352, 683, 1024 // 3 + 1]
+    for w in widths:
+        for h in (1, 15, 16, 17, 33):
+            f = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+            e.sharpen_kernel = np.array([[-1, -1, -1], [-1, 9, -1], [-1, -1, -1]])
+            assert np.array_equal(e.sharpen(f), oracle.filter3x3(f)), (w, h)
+    f = rng.integers(0, 256, size=(37, 344, 3), dtype=np.uint8)
+    for a, c in ((-1, 9), (1, 1), (-3, 25), (-14, 113), (-15, 121), (2, -3), (0, 1), (-1, 8)):
+        k = np.full((3, 3), a, np.float32)
+        k[1, 1] = c
+        e.sharpen_kernel = k
+        assert np.array_equal(e.sharpen(f), oracle.filter3x3(f, k)), (a, c)
+        assert np.array_equal(e.normalize_intensity(e.sharpen(f)), oracle.normalize_minmax(oracle.filter3x3(f, k))), (a, c)
+    # min / max folded out of the sharpen kernel must equal the materialised ones (process_pipeline uses them)
+    from chessboard_vision_amd import synth as S
+    e2 = ImageEnhancer()
+    e2.profile = {}
+    for w, h in ((343, 21), (16, 5), (352, 40)):
+        f = random_frame(w, h, w)
+        assert np.array_equal(e2.process_pipeline(f), oracle.process_pipeline(f, {})), (w, h)
