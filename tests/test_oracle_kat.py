@@ -32,6 +32,16 @@ def test_lab_white_black_and_roundtrip():
     assert np.abs(O.lab2bgr(O.bgr2lab(gray)).astype(int) - gray.astype(int)).max() <= 1
 
 
+def test_lab_values_opencv_is_publicly_known_to_return():
+    """The few OpenCV-side numbers that can be anchored without an OpenCV build: what `cv2.cvtColor(.., COLOR_BGR2LAB)`
+    returns for the primaries on 8-bit images is quoted all over OpenCV's forum / Q&A literature (red (136, 208, 195),
+    green (224, 42, 211), blue (82, 207, 20)), as are L = 137 for mid-gray 128 and the gray / HSV values of the
+    primaries above.  Written down from that public knowledge, not from a fixture: a weak pin, but a real one — the
+    integer Lab path with its gamma, cube-root and D65 tables has to be right to hit all nine values."""
+    px = np.array([[[0, 0, 255], [0, 255, 0], [255, 0, 0], [128, 128, 128]]], np.uint8)
+    assert O.bgr2lab(px)[0].tolist() == [[136, 208, 195], [224, 42, 211], [82, 207, 20], [137, 128, 128]]
+
+
 def test_convert_scale_abs_folds_negative():
     x = np.arange(256, dtype=np.uint8).reshape(1, 256)
     y = O.convert_scale_abs(x, 1.48, -30)
