@@ -38,6 +38,17 @@ for t, d, q in ev:
 span = rows[-1][1] - rows[0][0]
 print("kernels: %d on %d queues; span %.3f ms, some kernel running %.3f ms (%.1f %%), kernels of >= 2 queues at once %.3f ms (%.1f %% of the span)"
       % (len(rows), len({q for _, _, q, _ in rows}), span / 1e6, busy / 1e6, 100.0 * busy / span, multi / 1e6, 100.0 * multi / span))
+# how long are TWO launches of the dominant kernel in flight at once (both lanes in the bilateral: no complementary work)?
+bl = sorted((s, e) for s, e, q, n in rows if n == "k_bilateral")
+both = 0
+for i, (s1, e1) in enumerate(bl):
+    for s2, e2 in bl[i + 1:]:
+        if s2 >= e1:
+            break
+        both += min(e1, e2) - s2
+one = sum(e - s for s, e in bl) - 2 * both
+print("k_bilateral in flight: one launch %.3f ms (%.1f %% of the span), two launches at once %.3f ms (%.1f %%), none %.1f %%"
+      % (one / 1e6, 100.0 * one / span, both / 1e6, 100.0 * both / span, 100.0 * (span - one - both) / span))
 per = collections.defaultdict(list)
 for s, e, q, n in rows:
     per[n].append(e - s)
