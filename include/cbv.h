@@ -17,7 +17,11 @@
  *     the library keeps no host pointer after returning.
  *   - "dev" entry points take device pointers, enqueue on the context's
  *     stream and do not synchronise.
- *   - one cbv_ctx per GPU; a ctx is not thread-safe.
+ *   - one cbv_ctx per GPU is the intended use.  A ctx is ONE queue of work (shared scratch buffers, one current
+ *     stream): every entry point that touches the GPU holds the context's lock for its whole call, so calls from
+ *     several threads on one ctx (and on the cbv_squares / cbv_pipeline objects created on it) serialise; they never
+ *     run concurrently.  Use one ctx per thread for concurrency.  Host buffers passed to a call must stay valid and
+ *     unmodified until it returns; the pinned host ring (cbv_pipeline_host_ring) until cbv_pipeline_wait_submitted.
  *   - there is no CPU fallback: without a usable gfx950 device
  *     cbv_ctx_create() fails with CBV_ERR_NODEV.
  */
