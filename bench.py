@@ -54,6 +54,20 @@ def aggregate_fps(frames_per_rank, steps, world_size, elapsed_max_s):
     return frames_per_rank * steps * world_size / elapsed_max_s
 
 
+def rank_reduce(dist, backend, elapsed_s, occ_ok):
+    """What the ranks exchange: the MAX of their elapsed times and the AND of their occupancy checks (two tiny
+    all-reduces; the data path itself has no collective).  `dist` is torch.distributed or None for a single rank."""
+    if dist is None:
+        return elapsed_s, occ_ok
+    import torch
+    dev = "cuda" if backend == "nccl" else "cpu"
+    t = torch.tensor([elapsed_s], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    flag = torch.tensor([0 if occ_ok else 1], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    return float(t.item()), int(flag.item()) == 0
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -257,11 +271,7 @@ def main():
         step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        dist.barrier()
+    elapsed_local = elapsed
     torch.cuda.synchronize()
     bl_ms, bl_n = ctx.profile_read(N.K["BILATERAL"])
     ctx.profile_enable(-2)
@@ -273,10 +283,9 @@ def main():
     occ_ok = not bad and pipe.occupied(res[F - 1]) == set(S.position_for_frame(F - 1).keys())
     if not occ_ok:
         print("rank %d: occupancy differs from the scripted position on frames %s" % (rank, bad[:8]), file=sys.stderr)
+    elapsed, occ_ok = rank_reduce(dist, backend, elapsed_local, occ_ok)
     if dist is not None:
-        flag = torch.tensor([0 if occ_ok else 1], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        occ_ok = int(flag.item()) == 0
+        dist.barrier()
 
     per_kernel_bytes, path_bytes = algorithmic_bytes(w, h)
     fps = aggregate_fps(F, args.steps, world, elapsed)

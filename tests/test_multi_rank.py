@@ -26,14 +26,17 @@ def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     mine = bench.shard_streams(8, world, rank)
-    # per-rank "work": distinct streams, per-rank elapsed time; only the time is reduced (MAX)
-    elapsed = torch.tensor([0.5 + 0.25 * rank], dtype=torch.float64)
+    # per-rank "work": distinct streams, per-rank elapsed time; bench.py's own reduction: MAX of the times, AND of the
+    # occupancy checks (rank 1 reports a failed check in the second call)
     dist.barrier()
-    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    fps = bench.aggregate_fps(frames_per_rank=512, steps=4, world_size=world, elapsed_max_s=float(elapsed))
+    elapsed, ok = bench.rank_reduce(dist, "gloo", 0.5 + 0.25 * rank, True)
+    _, ok2 = bench.rank_reduce(dist, "gloo", 0.1, rank == 0)
+    assert ok and not ok2
+    assert bench.rank_reduce(None, "gloo", 1.25, True) == (1.25, True)
+    fps = bench.aggregate_fps(frames_per_rank=512, steps=4, world_size=world, elapsed_max_s=elapsed)
     gathered = [None] * world
     dist.all_gather_object(gathered, mine)
-    q.put((rank, mine, float(elapsed), fps, gathered))
+    q.put((rank, mine, elapsed, fps, gathered))
     dist.destroy_process_group()
 
 
