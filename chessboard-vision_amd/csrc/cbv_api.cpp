@@ -952,6 +952,8 @@ struct cbv_pipeline {
     size_t plane_total = 0;
     // ingest: pinned host mirror of the frame ring, filled by the capture side and copied on its own stream
     u8* host_ring = nullptr;
+    u8* h_stage = nullptr; // pinned: results travel device -> here -> the caller's (pageable) buffer, two async copies and ONE wait
+    size_t h_stage_bytes = 0;
     hipStream_t copy_stream = nullptr;
     struct CopyRec {
         int s0, cnt;
@@ -960,7 +962,8 @@ struct cbv_pipeline {
     };
     std::vector<CopyRec> copies;
     // The temporal scan (+ NoiseHandler) of a run goes to its own stream behind the lanes' events, so the next run's
-    // enhancement of OTHER slots overlaps it; scans of successive runs stay ordered on that stream.
+    // enhancement of OTHER slots overlaps it; scans of successive runs stay ordered on that stream.  (Runs of one or
+    // two frames keep their scan on the caller's stream, after waiting for every run in flight: see cbv_pipeline_run.)
     hipStream_t scan_stream = nullptr;
     hipEvent_t main_done = nullptr;
     // Every run that may still be executing: its slot range and two events on the (in-order) scan stream,
@@ -1080,6 +1083,7 @@ extern "C" void cbv_pipeline_destroy(cbv_pipeline* p)
     }
     for (auto& c : p->copies) (void)hipEventDestroy(c.ev);
     if (p->host_ring) (void)hipHostFree(p->host_ring);
+    if (p->h_stage) (void)hipHostFree(p->h_stage);
     if (p->frames) (void)hipFree(p->frames);
     if (p->enhanced) (void)hipFree(p->enhanced);
     if (p->warped) (void)hipFree(p->warped);
@@ -1348,7 +1352,16 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
     // Lane 0 is the context's stream; lanes 1.. are worker streams forked from it and joined before
     // the temporal scan (which needs every frame's statistics, in order).
     hipStream_t main_stream = ctx->stream;
-    RC(join_slots(p, slot0, count)); // scans in flight that still read these slots' planes, however many runs back
+    // A run of one or two frames (the live-camera case) is latency, not throughput: its scan is a few microseconds, less
+    // than the hop to the scan stream and back, so everything stays on the caller's stream, behind every run in flight
+    // (the scans' state is sequential over runs).
+    const bool inline_scan = count <= 2;
+    const int chunks = (count + p->chunk - 1) / p->chunk;
+    const int lanes_used = std::min(p->n_lanes, chunks);
+    if (inline_scan) {
+        retire_runs(p);
+        RC(join_scan(p));
+    } else RC(join_slots(p, slot0, count)); // scans in flight that still read these slots' planes, however many runs back
     cbv_pipeline::RunRec* rec = nullptr; // the record (and second-pass list) of this run
     for (auto& r : p->runs)
         if (!r.live) {
@@ -1371,9 +1384,9 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
             CBV_HIP(ctx, hipStreamWaitEvent(main_stream, c.ev, 0));
             c.pending = false;
         }
-    if (p->n_lanes > 1) {
+    if (lanes_used > 1) {
         CBV_HIP(ctx, hipEventRecord(p->start_ev, main_stream));
-        for (int l = 1; l < p->n_lanes; l++) CBV_HIP(ctx, hipStreamWaitEvent(p->lane_stream[l], p->start_ev, 0));
+        for (int l = 1; l < lanes_used; l++) CBV_HIP(ctx, hipStreamWaitEvent(p->lane_stream[l], p->start_ev, 0));
     }
     int ci = 0, rc_all = CBV_OK;
     for (int s0 = slot0; s0 < slot0 + count && rc_all == CBV_OK; s0 += p->chunk, ci++) {
@@ -1388,27 +1401,19 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
         rc_all = enhance_dev(ctx, src, p->A[lane], p->B[lane], p->g, &cfg.enhance, SL, b, !p->keep_enhanced, &res);
         if (rc_all) break;
         u8* wdst = p->warped + p->warped_stride * s0;
+        u32* work = cfg.use_hough ? (u32*)p->lane_work[lane].p : nullptr; // worklist counter: zeroed by k_warp
         if (p->keep_enhanced) {
             if (hipMemcpyAsync(p->enhanced + p->g.frame_stride * s0, res, p->g.frame_stride * b, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
                 rc_all = cbv_fail(ctx, CBV_ERR_HIP, "copy of the enhanced frames failed");
                 break;
             }
-            rc_all = launch_warp(ctx, res, p->g, p->Minv, S, S, cfg.rot180, wdst, S * 3, p->warped_stride, nullptr, b);
+            rc_all = launch_warp(ctx, res, p->g, p->Minv, S, S, cfg.rot180, wdst, S * 3, p->warped_stride, nullptr, b, work);
         } else {
-            rc_all = launch_warp(ctx, res, p->g, p->Minv, S, S, cfg.rot180, wdst, S * 3, p->warped_stride, SL.norm_lut, b);
+            rc_all = launch_warp(ctx, res, p->g, p->Minv, S, S, cfg.rot180, wdst, S * 3, p->warped_stride, SL.norm_lut, b, work);
         }
         if (rc_all) break;
         u8* dec = (u8*)p->d_dec.p + (size_t)CBV_MAX_SQUARES * s0;
-        u32* work = nullptr;
-        cbv_hough_result* hres = nullptr;
-        if (cfg.use_hough) {
-            work = (u32*)p->lane_work[lane].p;
-            hres = (cbv_hough_result*)p->d_hough.p + (size_t)CBV_MAX_SQUARES * s0;
-            if (hipMemsetAsync(work, 0, sizeof(u32), ctx->stream) != hipSuccess) {
-                rc_all = cbv_fail(ctx, CBV_ERR_HIP, "reset of the HoughCircles worklist failed");
-                break;
-            }
-        }
+        cbv_hough_result* hres = cfg.use_hough ? (cbv_hough_result*)p->d_hough.p + (size_t)CBV_MAX_SQUARES * s0 : nullptr;
         rc_all = launch_squares_pre5_stats(ctx, wdst, p->warped_stride, (const SquareDesc*)p->d_descs.p, n,
                                            (u8*)p->d_gray.p + p->plane_total * s0, p->plane_total,
                                            p->calibrated ? (const float*)p->d_mean.p : nullptr, p->calibrated ? (const float*)p->d_var.p : nullptr,
@@ -1425,15 +1430,18 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
         CBV_HIP(ctx, hipStreamCreateWithFlags(&p->scan_stream, hipStreamNonBlocking));
         CBV_HIP(ctx, hipEventCreateWithFlags(&p->main_done, hipEventDisableTiming));
     }
-    CBV_HIP(ctx, hipEventRecord(p->main_done, main_stream));
-    CBV_HIP(ctx, hipStreamWaitEvent(p->scan_stream, p->main_done, 0));
-    for (int l = 1; l < p->n_lanes; l++) {
-        CBV_HIP(ctx, hipEventRecord(p->lane_done[l], p->lane_stream[l]));
-        CBV_HIP(ctx, hipStreamWaitEvent(p->scan_stream, p->lane_done[l], 0));
+    hipStream_t scan_on = inline_scan ? main_stream : p->scan_stream;
+    if (!inline_scan) {
+        CBV_HIP(ctx, hipEventRecord(p->main_done, main_stream));
+        CBV_HIP(ctx, hipStreamWaitEvent(scan_on, p->main_done, 0));
+        for (int l = 1; l < lanes_used; l++) {
+            CBV_HIP(ctx, hipEventRecord(p->lane_done[l], p->lane_stream[l]));
+            CBV_HIP(ctx, hipStreamWaitEvent(scan_on, p->lane_done[l], 0));
+        }
     }
     // every lane has read its frames: a later cbv_pipeline_submit may overwrite these slots after this event
-    CBV_HIP(ctx, hipEventRecord(rec->lanes_ev, p->scan_stream));
-    ctx->stream = p->scan_stream;
+    CBV_HIP(ctx, hipEventRecord(rec->lanes_ev, scan_on));
+    ctx->stream = scan_on;
     struct Restore {
         cbv_ctx* c;
         hipStream_t s;
@@ -1455,14 +1463,13 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
             if ((double)sum / (double)len >= cfg.min_presence) sp.stable_table |= 1ull << (len * 8 + sum);
     sp.thr_is_int = (cfg.change_threshold == (double)(int)cfg.change_threshold && cfg.change_threshold >= 0 && cfg.change_threshold < 256) ? 1 : 0;
     sp.thr_int = (int)cfg.change_threshold;
+    // + NoiseHandler on the frames' visual_changes sets (game_session.py:165)
     RC(launch_scan(ctx, (const SquareDesc*)p->d_descs.p, sp, (const u8*)p->d_gray.p + p->plane_total * slot0, p->plane_total,
                    (const u8*)p->d_dec.p + (size_t)CBV_MAX_SQUARES * slot0, (u8*)p->d_ref.p, (ScanState*)p->d_state.p,
                    (u8*)p->d_flags.p + (size_t)CBV_MAX_SQUARES * slot0, (cbv_frame_result*)p->d_results.p + slot0, count,
-                   p->has_check ? (const u64*)p->d_check.p + slot0 : nullptr));
-    // NoiseHandler on the frames' visual_changes sets (game_session.py:165)
-    RC(launch_noise(ctx, &((const cbv_frame_result*)p->d_results.p + slot0)->visual_changes, sizeof(cbv_frame_result) / 8, count,
-                    (cbv_noise_state*)p->d_noise_state.p, (cbv_noise_result*)p->d_noise.p + slot0));
-    CBV_HIP(ctx, hipEventRecord(rec->scan_ev, p->scan_stream));
+                   p->has_check ? (const u64*)p->d_check.p + slot0 : nullptr, (cbv_noise_state*)p->d_noise_state.p,
+                   (cbv_noise_result*)p->d_noise.p + slot0));
+    CBV_HIP(ctx, hipEventRecord(rec->scan_ev, scan_on));
     rec->s0 = slot0;
     rec->cnt = count;
     rec->seq = ++p->run_seq;
@@ -1490,11 +1497,28 @@ extern "C" int cbv_pipeline_results(cbv_pipeline* p, int slot0, int count, cbv_f
     cbv_ctx* ctx = p->ctx;
     CBV_ENTER(ctx);
     RC(join_scan(p)); // lanes and scan of the last run
-    CBV_HIP(ctx, hipMemcpyAsync(out, (cbv_frame_result*)p->d_results.p + slot0, sizeof(cbv_frame_result) * count, hipMemcpyDeviceToHost, ctx->stream));
-    u32 over = 0;
+    // through a pinned staging buffer: a copy into the caller's pageable memory is staged by the runtime anyway, one
+    // blocking copy at a time (two of them cost ~45 us per call, a fifth of a single-frame run)
+    const size_t bytes = sizeof(cbv_frame_result) * (size_t)count;
+    if (p->h_stage_bytes < bytes + 16) {
+        if (p->h_stage) (void)hipHostFree(p->h_stage);
+        p->h_stage = nullptr;
+        p->h_stage_bytes = 0;
+        const size_t want = sizeof(cbv_frame_result) * (size_t)p->max_frames + 16;
+        if (hipHostMalloc((void**)&p->h_stage, want, hipHostMallocDefault) != hipSuccess) {
+            p->h_stage = nullptr;
+            return cbv_fail(ctx, CBV_ERR_HIP, "pinned staging buffer for results (%zu bytes) failed", want);
+        }
+        p->h_stage_bytes = want;
+    }
+    u32* over_h = (u32*)(p->h_stage + ((bytes + 7) & ~(size_t)7));
+    *over_h = 0;
+    CBV_HIP(ctx, hipMemcpyAsync(p->h_stage, (cbv_frame_result*)p->d_results.p + slot0, bytes, hipMemcpyDeviceToHost, ctx->stream));
     if (p->configured && p->cfg.use_hough && p->d_hough_over.p)
-        CBV_HIP(ctx, hipMemcpyAsync(&over, p->d_hough_over.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+        CBV_HIP(ctx, hipMemcpyAsync(over_h, p->d_hough_over.p, 4, hipMemcpyDeviceToHost, ctx->stream));
     CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(out, p->h_stage, bytes);
+    const u32 over = *over_h;
     if (over) // a truncated candidate list may change has_piece: never hand that over as if it were HoughCircles' answer
         return cbv_fail(ctx, CBV_ERR_UNSUPPORTED, "HoughCircles: the candidate list overflowed (more than 512 accumulator maxima) on %u square(s) "
                         "since the last reset_state; those occupancy bits are not HoughCircles' (inspect cbv_pipeline_hough flags)", over);

@@ -185,7 +185,7 @@ int launch_sharpen(cbv_ctx* ctx, const u8* src, u8* dst, u32* aux, int tiles, Ge
 int launch_norm_lut(cbv_ctx* ctx, const u32* aux, int tiles, u8* norm_lut, int batch);
 int launch_normalize(cbv_ctx* ctx, const u8* src, u8* dst, const u8* norm_lut, Geom g, int batch);
 int launch_warp(cbv_ctx* ctx, const u8* src, Geom g, const double* Minv9, int dw, int dh, int rot180, u8* dst,
-                int dst_stride, size_t dst_frame_stride, const u8* norm_lut, int batch);
+                int dst_stride, size_t dst_frame_stride, const u8* norm_lut, int batch, u32* zero_word = nullptr);
 int launch_gray_blur_hist(cbv_ctx* ctx, const u8* src, u8* gray, u8* blur, u32* aux, int tiles, Geom g, int batch);
 int launch_otsu(cbv_ctx* ctx, u32* aux, int tiles, int total, int batch);
 int launch_threshold(cbv_ctx* ctx, const u8* blur, u8* binary, const u32* aux, int tiles, int w, int h, int batch);
@@ -269,4 +269,4 @@ int launch_scan_update_refs(cbv_ctx* ctx, const SquareDesc* descs, int n, const 
 int launch_noise(cbv_ctx* ctx, const u64* changes, size_t stride_words, int count, cbv_noise_state* state, cbv_noise_result* out);
 int launch_scan(cbv_ctx* ctx, const SquareDesc* descs, ScanParams sp, const u8* gray, size_t gray_frame_stride,
                 const u8* decisions, u8* ref, ScanState* state, u8* flags, cbv_frame_result* results, int count,
-                const u64* check = nullptr);
+                const u64* check = nullptr, cbv_noise_state* noise_state = nullptr, cbv_noise_result* noise_out = nullptr);

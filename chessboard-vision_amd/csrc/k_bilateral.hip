@@ -261,6 +261,19 @@ int launch_bilateral(cbv_ctx* ctx, const u8* src, u8* dst, Geom g, int batch)
     // BESIDE it instead of waiting for its persistent workgroups to end; the whole path gains 2-3 %
     // (gpurun sweep, 1080p x 512: 640 lanes 26.0 k frames/s, 768 27.8 k, 896 25.5 k, 1024 27.2 k, 2 x 512 25.9 k).
     constexpr int NT = 768;
+    // One or two frames (the live-camera case) are too few 128 x 48 tiles for 256 persistent workgroups (a 1080p frame has
+    // 345: the second round is a third full).  128 x 32 tiles on TWO 512-lane workgroups per CU (2 x 52 KB of LDS, the
+    // same 4 waves per SIMD as one 1024-lane workgroup) put 510 tiles on 512 workgroups in one round.
+    {
+        const long long t768 = (long long)((g.w + BL_TW - 1) / BL_TW) * ((g.h + NT / 16 - 1) / (NT / 16)) * batch;
+        if (t768 < 2ll * ctx->num_cus) switch (ctx->btabs_host.radius) {
+            case 1: return launch_bilateral_r<1, 512>(ctx, src, dst, g, batch, 2);
+            case 2: return launch_bilateral_r<2, 512>(ctx, src, dst, g, batch, 2);
+            case 3: return launch_bilateral_r<3, 512>(ctx, src, dst, g, batch, 2);
+            case 4: return launch_bilateral_r<4, 512>(ctx, src, dst, g, batch, 2);
+            default: break;
+            }
+    }
     switch (ctx->btabs_host.radius) {
     case 1: return launch_bilateral_r<1, NT>(ctx, src, dst, g, batch, 1);
     case 2: return launch_bilateral_r<2, NT>(ctx, src, dst, g, batch, 1);

@@ -437,7 +437,10 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const u8* __restrict__ lab,
 
 int launch_clahe_apply(cbv_ctx* ctx, const u8* lab, const u32* packed, u8* dst, Geom g, ClaheGeom cg, int batch)
 {
-    const int rows_per_wg = 8;
+    // 8 rows per workgroup amortise the 18 KB of tables it stages; a launch of one or two frames (the live-camera
+    // case) would then put only ~150 workgroups on 256 CUs, so small batches take fewer rows, down to one
+    int rows_per_wg = 8;
+    while (rows_per_wg > 1 && (size_t)((cg.th + rows_per_wg) / rows_per_wg) * (cg.tiles_y + 1) * batch < 1024) rows_per_wg >>= 1;
     int tiles = cg.tiles_x * cg.tiles_y;
     if (cg.tiles_x > CLAHE_MAX_TILES_X) return cbv_fail(ctx, CBV_ERR_UNSUPPORTED, "clahe: tile grid wider than %d (%d)", CLAHE_MAX_TILES_X, cg.tiles_x);
     // a band is at most th rows (+1 for rounding)

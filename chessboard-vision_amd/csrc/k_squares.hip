@@ -224,7 +224,7 @@ __device__ __forceinline__ void sq_accum_px(SqAccum& A, int gv, u32 mk, bool has
     }
 }
 
-// block reduction + the record and the decision byte (thread 0).  acc[20], zm[4], nanf_[1] are LDS, zeroed and
+// block reduction + the record and the decision byte (thread 0).  acc[20], zm[waves], nanf_[1] are LDS, zeroed and
 // synchronised by the caller before any lane gets here.
 __device__ __forceinline__ void sq_accum_finish(SqAccum& A, u32* acc, float* zm, int* nanf_, int n, bool has_model,
                                                 cbv_sq_stats* __restrict__ out, int nsq, u8* __restrict__ decisions,
@@ -255,7 +255,8 @@ __device__ __forceinline__ void sq_accum_finish(SqAccum& A, u32* acc, float* zm,
             st.ring_cnt[k] = acc[11 + k];
         }
         st.z_count = acc[15];
-        float z = fmaxf(fmaxf(zm[0], zm[1]), fmaxf(zm[2], zm[3]));
+        float z = zm[0];
+        for (int k = 1; k < (int)(blockDim.x >> 6); k++) z = fmaxf(z, zm[k]);
         st.z_max = nanf_[0] ? __builtin_nanf("") : z;
         out[(size_t)blockIdx.z * nsq + blockIdx.x] = st;
         if (decisions) {
@@ -312,7 +313,10 @@ __global__ __launch_bounds__(256) void k_squares_stats(const SquareDesc* __restr
 
 // preprocess (k = 5) and statistics of the pipeline in one pass: the statistics are sums over the plane the blur
 // produces, so they are taken as the pixels leave the vertical pass (one launch and one read of the plane less)
-__global__ __launch_bounds__(256) void k_squares_pre5_stats(const u8* __restrict__ src, size_t src_frame_stride,
+// NT lanes per square: 256 in batched launches (the chip is full of squares), 1024 when a launch holds only a frame or
+// two (64-128 squares on 256 CUs: then a square's three passes are latency, and four times the lanes cut it).
+template <int NT>
+__global__ __launch_bounds__(NT) void k_squares_pre5_stats(const u8* __restrict__ src, size_t src_frame_stride,
                                                              const SquareDesc* __restrict__ descs, u8* __restrict__ gray,
                                                              size_t gray_frame_stride, const float* __restrict__ mean,
                                                              const float* __restrict__ var, const u8* __restrict__ masks,
@@ -322,7 +326,7 @@ __global__ __launch_bounds__(256) void k_squares_pre5_stats(const u8* __restrict
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     __shared__ u32 acc[20];
-    __shared__ float zm[4];
+    __shared__ float zm[NT / 64];
     __shared__ int nanf_[1];
     const SquareDesc d = descs[blockIdx.x];
     const int w = d.w, h = d.h, n = w * h;
@@ -334,13 +338,13 @@ __global__ __launch_bounds__(256) void k_squares_pre5_stats(const u8* __restrict
     if (threadIdx.x == 0) nanf_[0] = 0;
     {
         const int ngx = (w + 3) >> 2, ntask = ngx * h;
-        for (int t0 = threadIdx.x; t0 < ntask; t0 += 4 * 256) {
+        for (int t0 = threadIdx.x; t0 < ntask; t0 += 4 * NT) {
             u32 v[4][3];
             int yy[4], xx[4];
             bool full[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const int t = t0 + q * 256;
+                const int t = t0 + q * NT;
                 full[q] = false;
                 if (t < ntask) {
                     yy[q] = t / ngx;
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(256) void k_squares_pre5_stats(const u8* __restrict
             }
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const int t = t0 + q * 256;
+                const int t = t0 + q * NT;
                 if (t >= ntask) continue;
                 u8* o = g + yy[q] * w + xx[q];
                 if (full[q]) {
@@ -369,7 +373,7 @@ __global__ __launch_bounds__(256) void k_squares_pre5_stats(const u8* __restrict
     __syncthreads();
     for (int x = tx; x < w; x += 16) {
         const int x0 = d_reflect101(x - 2, w), x1 = d_reflect101(x - 1, w), x3 = d_reflect101(x + 1, w), x4 = d_reflect101(x + 2, w);
-        for (int y = ty; y < h; y += 16) {
+        for (int y = ty; y < h; y += NT / 16) {
             const u8* r = g + y * w;
             hb[y * w + x] = (u16)(16 * (r[x0] + r[x4]) + 64 * (r[x1] + r[x3]) + 96 * r[x]);
         }
@@ -381,7 +385,7 @@ __global__ __launch_bounds__(256) void k_squares_pre5_stats(const u8* __restrict
     const float* vp = mean ? var + d.plane_off : nullptr;
     SqAccum A;
     sq_accum_init(A);
-    for (int y = ty; y < h; y += 16) {
+    for (int y = ty; y < h; y += NT / 16) {
         const int y0 = d_reflect101(y - 2, h) * w, y1 = d_reflect101(y - 1, h) * w, y3 = d_reflect101(y + 1, h) * w, y4 = d_reflect101(y + 2, h) * w;
         for (int x = tx; x < w; x += 16) {
             const u32 a2 = 16u * (hb[y0 + x] + hb[y4 + x]) + 64u * (hb[y1 + x] + hb[y3 + x]) + 96u * hb[y * w + x];
@@ -402,8 +406,12 @@ int launch_squares_pre5_stats(cbv_ctx* ctx, const u8* src, size_t src_frame_stri
     if (max_px <= 0 || max_px > CBV_MAX_SQUARE_DIM * CBV_MAX_SQUARE_DIM) max_px = CBV_MAX_SQUARE_DIM * CBV_MAX_SQUARE_DIM;
     const size_t lds = (size_t)((max_px + 15) & ~15) + 2 * (size_t)max_px;
     prof_begin(ctx, CBV_K_SQUARES);
-    hipLaunchKernelGGL(k_squares_pre5_stats, dim3(n, 1, batch), dim3(256), lds, ctx->stream, src, src_frame_stride, descs, gray,
-                       gray_frame_stride, mean, var, masks, z_thresh, out, n, decisions, want_hough, hough_work, hough_out);
+    if ((long long)n * batch <= 2 * ctx->num_cus)
+        hipLaunchKernelGGL(k_squares_pre5_stats<1024>, dim3(n, 1, batch), dim3(1024), lds, ctx->stream, src, src_frame_stride, descs, gray,
+                           gray_frame_stride, mean, var, masks, z_thresh, out, n, decisions, want_hough, hough_work, hough_out);
+    else
+        hipLaunchKernelGGL(k_squares_pre5_stats<256>, dim3(n, 1, batch), dim3(256), lds, ctx->stream, src, src_frame_stride, descs, gray,
+                           gray_frame_stride, mean, var, masks, z_thresh, out, n, decisions, want_hough, hough_work, hough_out);
     prof_end(ctx, CBV_K_SQUARES);
     CBV_HIP(ctx, hipGetLastError());
     return CBV_OK;
@@ -656,10 +664,9 @@ __global__ void k_pack_results(const u8* __restrict__ flags, int n, cbv_frame_re
 // NoiseHandler.process (noise_handler.py:49-213): a 3-state machine over the per-frame set of
 // visually changed squares.  Sequential and tiny: one lane walks the frames.
 // ---------------------------------------------------------------------------
-__global__ void k_noise(const u64* __restrict__ changes, size_t stride_words, int count, cbv_noise_state* __restrict__ state,
-                        cbv_noise_result* __restrict__ out)
+__device__ void d_noise_run(const u64* __restrict__ changes, size_t stride_words, int count, cbv_noise_state* __restrict__ state,
+                            cbv_noise_result* __restrict__ out)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const int NOISE_THRESHOLD = 3, STABILITY_FRAMES = 12, COOLDOWN_FRAMES = 5;
     cbv_noise_state s = *state;
     for (int t = 0; t < count; t++) {
@@ -717,6 +724,33 @@ __global__ void k_noise(const u64* __restrict__ changes, size_t stride_words, in
     *state = s;
 }
 
+__global__ void k_noise(const u64* __restrict__ changes, size_t stride_words, int count, cbv_noise_state* __restrict__ state,
+                        cbv_noise_result* __restrict__ out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    d_noise_run(changes, stride_words, count, state, out);
+}
+
+// k_pack_results + k_noise of a run of at most four frames (one workgroup packs them all) in ONE launch: on a run of
+// one frame every launch in the chain is ~4.5 us of latency
+__global__ __launch_bounds__(256) void k_pack_noise(const u8* __restrict__ flags, int n, cbv_frame_result* __restrict__ results, int count,
+                                                     cbv_noise_state* __restrict__ state, cbv_noise_result* __restrict__ out)
+{
+    const int t = threadIdx.x >> 6, sq = threadIdx.x & 63;
+    if (t < count) {
+        const u32 fl = sq < n ? flags[(size_t)t * CBV_MAX_SQUARES + sq] : 0u;
+        u64* r = (u64*)&results[t];
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const u64 m = __ballot((fl >> b) & 1u);
+            if (sq == 0) r[b] = m;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (threadIdx.x == 0) d_noise_run(&results[0].visual_changes, sizeof(cbv_frame_result) / 8, count, state, out);
+}
+
 int launch_noise(cbv_ctx* ctx, const u64* changes, size_t stride_words, int count, cbv_noise_state* state, cbv_noise_result* out)
 {
     hipLaunchKernelGGL(k_noise, dim3(1), dim3(64), 0, ctx->stream, changes, stride_words, count, state, out);
@@ -726,13 +760,19 @@ int launch_noise(cbv_ctx* ctx, const u64* changes, size_t stride_words, int coun
 
 int launch_scan(cbv_ctx* ctx, const SquareDesc* descs, ScanParams sp, const u8* gray, size_t gray_frame_stride,
                 const u8* decisions, u8* ref, ScanState* state, u8* flags, cbv_frame_result* results, int count,
-                const u64* check)
+                const u64* check, cbv_noise_state* noise_state, cbv_noise_result* noise_out)
 {
+    // noise_state != null: NoiseHandler over the frames' visual_changes sets follows the scan (game_session.py:165)
     prof_begin(ctx, CBV_K_SCAN);
     hipLaunchKernelGGL(k_scan, dim3(sp.n), dim3(64), 0, ctx->stream, descs, sp, gray, gray_frame_stride, decisions, ref,
                        state, flags, count, check);
-    hipLaunchKernelGGL(k_pack_results, dim3((count + 3) / 4), dim3(256), 0, ctx->stream, flags, sp.n, results, count);
+    if (noise_state && count <= 4)
+        hipLaunchKernelGGL(k_pack_noise, dim3(1), dim3(256), 0, ctx->stream, flags, sp.n, results, count, noise_state, noise_out);
+    else
+        hipLaunchKernelGGL(k_pack_results, dim3((count + 3) / 4), dim3(256), 0, ctx->stream, flags, sp.n, results, count);
     prof_end(ctx, CBV_K_SCAN);
     CBV_HIP(ctx, hipGetLastError());
+    if (noise_state && count > 4)
+        return launch_noise(ctx, &results->visual_changes, sizeof(cbv_frame_result) / 8, count, noise_state, noise_out);
     return CBV_OK;
 }

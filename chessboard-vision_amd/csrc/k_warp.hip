@@ -17,9 +17,12 @@ struct WarpM {
 
 __global__ __launch_bounds__(256) void k_warp(const u8* __restrict__ src, Geom g, WarpM M, int dw, int dh, int bw0,
                                                int bh0, int rot180, u8* __restrict__ dst, int dst_stride,
-                                               size_t dst_frame_stride, const u8* __restrict__ norm_lut)
+                                               size_t dst_frame_stride, const u8* __restrict__ norm_lut, u32* __restrict__ zero_word)
 {
     __shared__ u8 lut[256];
+    // the pipeline's HoughCircles worklist counter, filled by the NEXT kernel in the stream (k_squares_pre5_stats):
+    // zeroed here instead of by a 4-byte memset, which is one more ~4.5 us launch in a single-frame run
+    if (zero_word && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) *zero_word = 0u;
     const bool use_lut = norm_lut != nullptr;
     if (use_lut) lut[threadIdx.x] = norm_lut[(size_t)blockIdx.z * 256 + threadIdx.x];
     __syncthreads();
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(256) void k_warp(const u8* __restrict__ src, Geom g
 }
 
 int launch_warp(cbv_ctx* ctx, const u8* src, Geom g, const double* Minv9, int dw, int dh, int rot180, u8* dst,
-                int dst_stride, size_t dst_frame_stride, const u8* norm_lut, int batch)
+                int dst_stride, size_t dst_frame_stride, const u8* norm_lut, int batch, u32* zero_word)
 {
     WarpM M;
     for (int i = 0; i < 9; i++) M.m[i] = Minv9[i];
@@ -99,7 +102,7 @@ int launch_warp(cbv_ctx* ctx, const u8* src, Geom g, const double* Minv9, int dw
     dim3 grid((dw + 63) / 64, (dh + 3) / 4, batch);
     prof_begin(ctx, CBV_K_WARP);
     hipLaunchKernelGGL(k_warp, grid, dim3(256), 0, ctx->stream, src, g, M, dw, dh, bw0, bh0, rot180, dst, dst_stride,
-                       dst_frame_stride, norm_lut);
+                       dst_frame_stride, norm_lut, zero_word);
     prof_end(ctx, CBV_K_WARP);
     CBV_HIP(ctx, hipGetLastError());
     return CBV_OK;

@@ -95,6 +95,42 @@ def test_state_carries_across_runs_and_resets(gpu_ctx):
     assert whole[0][3] == 0xFFFFFFFFFFFFFFFF and whole[0][2] == 0xFFFFFFFFFFFFFFFF  # first frame: no reference yet
 
 
+def test_frame_at_a_time_equals_one_batched_run(gpu_ctx):
+    """The live-camera way of calling (one or two frames per run: scan on the caller's stream, small-batch launch
+    geometries of CLAHE apply / bilateral / squares, pack + NoiseHandler in one launch) gives what ONE run over all the
+    frames gives: warped boards, per-frame results, NoiseHandler outputs, HoughCircles records."""
+    from chessboard_vision_amd.stream import BoardPipeline
+    n = 24
+    pts = S.scaled_corners(W, H)
+    p = BoardPipeline(W, H, n)
+    p.configure(pts, profile=S.SHIPPED_PROFILE, chunk=8, lanes=2, **S.SHIPPED_DETECTOR)
+    p.synth(0, n, scene="dim", frames_per_ply=3)
+
+    def snapshot():
+        res = [(r.raw_occupied, r.stable_occupied, r.visual_changes, r.processed) for r in p.results(0, n)]
+        hough = [[(h.flags, h.found, h.cx, h.cy, h.r) for h in p.hough(i)] for i in range(n)]
+        return res, p.noise_results(0, n), [p.download(2, i) for i in range(n)], hough
+
+    p.run(0, n)
+    whole = snapshot()
+    for sizes in ((1,) * n, (2, 1, 4, 1, 5, 3, 2, 6)):
+        assert sum(sizes) == n
+        p.reset_state()
+        s0 = 0
+        for c in sizes:
+            p.run(s0, c)
+            if c == 1:
+                p.results(s0, 1)  # a live caller reads every frame's result before the next one arrives
+            s0 += c
+        got = snapshot()
+        assert got[0] == whole[0]
+        assert got[1] == whole[1]
+        for a, b in zip(got[2], whole[2]):
+            assert np.array_equal(a, b)
+        assert got[3] == whole[3]
+    p.close()
+
+
 def test_upload_path_equals_synth_path(gpu_ctx):
     from chessboard_vision_amd.stream import BoardPipeline
     pts = S.scaled_corners(W, H)
