@@ -100,6 +100,27 @@ class PieceDetectorHIP:
             result.update(has_piece=True, center=(w // 2, h // 2), radius=min(h, w) // 3, method="symmetry", confidence=symmetry)
         return result
 
+    def _gray_stats(self, gray):
+        """cbv_sq_stats (mask sums on the device) of one already preprocessed gray square."""
+        self._scratch.load({0: gray}, 5)          # geometry; the plane is replaced by `gray` as given
+        self._scratch.set(GRAY, 0, gray)
+        return self._scratch.stats()[0]
+
+    def _detect_center_vs_border(self, gray):
+        """(diff, center_mean, border_mean), piece_detector.py:177-207: means over the centre disc and the four corners."""
+        st = self._gray_stats(gray)
+        center_mean = np.float64(st.center_sum) / st.center_cnt if st.center_cnt else np.float64("nan")
+        border_mean = np.float64(st.border_sum) / st.border_cnt if st.border_cnt else np.float64("nan")
+        return abs(center_mean - border_mean), center_mean, border_mean
+
+    def _analyze_radial_symmetry(self, gray):
+        """0..1 score, piece_detector.py:141-175: variance of the mean intensity over four concentric rings / 500."""
+        st = self._gray_stats(gray)
+        ring_means = [np.float64(st.ring_sum[k]) / st.ring_cnt[k] for k in range(4) if st.ring_cnt[k] > 0]
+        if len(ring_means) < 2:
+            return 0.0
+        return min(1.0, np.var(ring_means) / 500)
+
     def _preprocess_square(self, square_img):
         self._scratch.load({0: square_img}, 5)
         return self._scratch.get(0, 0)

@@ -179,3 +179,18 @@ def test_refine_grid_matches_reference_run(gpu_ctx):
         gx, gy = ge.refine_grid(warped)
         assert [int(v) for v in gx] == rec["grid_x"] and [int(v) for v in gy] == rec["grid_y"]
         assert len(ge.split_board(warped)) == rec["n_squares"]
+
+
+@pytest.mark.gpu
+def test_mask_sums_of_the_hip_class_equal_the_reference_numpy(gpu_ctx):
+    """`_detect_center_vs_border` / `_analyze_radial_symmetry` of the HIP class (device mask sums) on the ten gray
+    squares of tests/golden/piece_numpy.npz == what the reference's methods returned for them (piece_detector.py:141-207,
+    recorded by make_goldens.py; pure numpy on the reference's side, so this row is pinned for real)."""
+    import os
+    from chessboard_vision_amd.piece_detector import PieceDetector
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "piece_numpy.npz"))
+    pd = PieceDetector()
+    for i in range(len(z["radial_symmetry"])):
+        g = np.ascontiguousarray(z["gray_%d" % i])
+        assert list(pd._detect_center_vs_border(g)) == z["center_vs_border"][i].tolist(), i
+        assert pd._analyze_radial_symmetry(g) == z["radial_symmetry"][i], i
