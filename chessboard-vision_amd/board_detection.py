@@ -2,7 +2,7 @@
 
 warp_image and reorder are the hot path's; find_chessboard_corners is the widening row f3 (pixel
 stages on the GPU, contour following on the host inside the same library).  The overlay-drawing helpers of the
-reference module (board_detection.py:74-146) are UI code and are not part of this package."""
+reference module (board_detection.py:84-146) are UI code and are not part of this package."""
 import ctypes as C
 
 import numpy as np
@@ -56,6 +56,12 @@ def warp_image(img, points, display_size=(1280, 720), margin=100):
     matrix = get_perspective_transform(pts1, pts2)
     warped = warp_perspective(img, matrix, (board_size, board_size))
     return warped, matrix, board_size
+
+
+def crop_inner_squares(img_warped, board_size, offset=0):
+    """The warped board without an `offset`-pixel border, as a view, and the new board size (board_detection.py:74-82)."""
+    cropped = img_warped[offset:board_size - offset, offset:board_size - offset]
+    return cropped, board_size - 2 * offset
 
 
 def corners_from_edges(edges):

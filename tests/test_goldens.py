@@ -203,3 +203,14 @@ def test_corners_from_edges_known_answers():
     edge[0:400, 0:300] = 255
     p3, _ = corners_from_edges(edge)
     assert sorted(p3.reshape(4, 2).tolist()) == [[0, 0], [0, 399], [299, 0], [299, 399]]
+
+
+def test_crop_inner_squares_is_a_view_like_the_reference():
+    """board_detection.py:74-82: a slice of the warped board (a view, not a copy) and the shrunken board size."""
+    from chessboard_vision_amd.board_detection import crop_inner_squares
+    w = np.arange(620 * 620 * 3, dtype=np.uint32).astype(np.uint8).reshape(620, 620, 3)
+    c, n = crop_inner_squares(w, 620, 2)
+    assert n == 616 and c.shape == (616, 616, 3) and c.base is not None and np.shares_memory(c, w)
+    assert np.array_equal(c, w[2:618, 2:618])
+    c0, n0 = crop_inner_squares(w, 620)
+    assert n0 == 620 and c0.shape == w.shape
