@@ -98,7 +98,7 @@ class PipelineConfig(C.Structure):
                 ("n_rois", C.c_int32), ("rois", Roi * MAX_SQUARES), ("history_size", C.c_int32),
                 ("min_presence", C.c_double), ("change_threshold", C.c_double), ("chunk", C.c_int32),
                 ("lanes", C.c_int32), ("z_threshold", C.c_double), ("initial_variance", C.c_double), ("keep_enhanced", C.c_int32),
-                ("use_hough", C.c_int32), ("hough", HoughParams)]
+                ("use_hough", C.c_int32), ("hough", HoughParams), ("enhance_region", C.c_int32)]
 
 
 class FrameResult(C.Structure):

@@ -1,5 +1,6 @@
 // C-ABI of libcbv_hip.so (include/cbv.h): context, host-buffer stage entry
 // points, per-square detector state and the device-resident batched pipeline.
+#include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -527,8 +528,20 @@ extern "C" int cbv_find_chessboard_corners(cbv_ctx* ctx, const uint8_t* bgr, int
 
 // enhancement chain on device buffers: src -> (A, B ping-pong) ; result pointer returned.
 // When `fold_norm` the final normalize pass is skipped and the caller applies S.norm_lut downstream.
+static PxRect px_dilate(PxRect r, int d, Geom g)
+{
+    PxRect o = {r.x0 - d, r.y0 - d, r.x1 + d, r.y1 + d};
+    o.x0 = o.x0 < 0 ? 0 : o.x0;
+    o.y0 = o.y0 < 0 ? 0 : o.y0;
+    o.x1 = o.x1 > g.w ? g.w : o.x1;
+    o.y1 = o.y1 > g.h ? g.h : o.y1;
+    return o;
+}
+
+// `region` (with a third buffer C, and only when the caller folds normalize into its own gather): the consumer samples
+// just these pixels of the enhanced frame; see "Region-limited enhancement" in cbv_internal.h.
 static int enhance_dev(cbv_ctx* ctx, const u8* src, u8* A, u8* B, Geom g, const cbv_enhance_params* P, SmallLayout S,
-                       int batch, bool fold_norm, u8** result)
+                       int batch, bool fold_norm, u8** result, const PxRect* region = nullptr, u8* C = nullptr)
 {
     ClaheGeom cg = clahe_geom(g.w, g.h, P->clahe_clip_limit, P->tiles_x, P->tiles_y);
     int tiles = P->tiles_x * P->tiles_y;
@@ -536,6 +549,28 @@ static int enhance_dev(cbv_ctx* ctx, const u8* src, u8* A, u8* B, Geom g, const 
     RC(launch_color_lab_hist(ctx, src, A, S.aux, g, cg, batch, P->profile.enabled ? 1 : 0, 1));
     if (!S.packed) return cbv_fail(ctx, CBV_ERR_STATE, "enhance_dev: the small-buffer layout lacks the packed CLAHE words");
     RC(launch_clahe_lut(ctx, S.aux, S.luts, cg, batch, S.packed));
+    if (region && C && fold_norm && sharpen_region_ok(P->sharpen_kernel) && region->x1 > region->x0 && region->y1 > region->y0) {
+        // what each stage must find complete in its input: the stage after it, rounded out to that stage's tiles, plus
+        // that stage's halo (sharpen 1 px, bilateral 4 px as staged)
+        const PxRect s_need = px_dilate(*region, 0, g);
+        const PxRect b_need = px_dilate(sharpen_region_cover(g, s_need), 1, g);
+        const PxRect c_need = px_dilate(bilateral_region_cover(ctx, g, batch, b_need), 4, g);
+        EnhanceRegion ec = {c_need, 0, {nullptr, 0}}, eb = {b_need, 0, {nullptr, 0}}, es = {s_need, 0, {nullptr, 0}};
+        // the sharpened frame goes to a THIRD buffer: the complement pass of the bilateral still reads CLAHE's output
+        // (B) in a ring inside the region, and that of sharpen the bilateral's (A)
+        RC(launch_clahe_apply(ctx, A, S.packed, B, g, cg, batch, &ec));
+        RC(launch_bilateral(ctx, B, A, g, batch, &eb));
+        RC(launch_sharpen(ctx, A, C, S.aux, tiles, g, P->sharpen_kernel, batch, &es));
+        const SatGate gate = {S.aux + (size_t)tiles * 256, aux_words(tiles)}; // min, max of frame 0 (k_sharpen_box)
+        ec.invert = eb.invert = es.invert = 1;
+        ec.gate = eb.gate = es.gate = gate;
+        RC(launch_clahe_apply(ctx, A, S.packed, B, g, cg, batch, &ec));
+        RC(launch_bilateral(ctx, B, A, g, batch, &eb));
+        RC(launch_sharpen(ctx, A, C, S.aux, tiles, g, P->sharpen_kernel, batch, &es));
+        RC(launch_norm_lut(ctx, S.aux, tiles, S.norm_lut, batch));
+        *result = C;
+        return CBV_OK;
+    }
     RC(launch_clahe_apply(ctx, A, S.packed, B, g, cg, batch));
     RC(launch_bilateral(ctx, B, A, g, batch));
     RC(launch_sharpen(ctx, A, B, S.aux, tiles, g, P->sharpen_kernel, batch));
@@ -939,6 +974,9 @@ struct cbv_pipeline {
     hipEvent_t start_ev = nullptr;
     u8* A[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
     u8* B[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+    u8* C[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr}; // third scratch frame set: region-limited enhancement only
+    bool use_region = false;                                  // cfg.enhance_region, keep_enhanced == 0, a usable footprint
+    PxRect region = {0, 0, 0, 0};                             // source pixels the warp samples (+ margin), clipped
     DevBuf lane_small[MAX_LANES];
     DevBuf lane_work[MAX_LANES]; // HoughCircles worklist of the lane's current chunk: count, then frame << 8 | square
     u8* enhanced = nullptr; // [max_frames] when keep_enhanced
@@ -1061,6 +1099,7 @@ extern "C" void cbv_pipeline_destroy(cbv_pipeline* p)
         if (p->lane_stream[l]) (void)hipStreamSynchronize(p->lane_stream[l]);
         if (p->A[l]) (void)hipFree(p->A[l]);
         if (p->B[l]) (void)hipFree(p->B[l]);
+        if (p->C[l]) (void)hipFree(p->C[l]);
         dev_free(&p->lane_small[l]);
         dev_free(&p->lane_work[l]);
         if (p->lane_done[l]) (void)hipEventDestroy(p->lane_done[l]);
@@ -1131,7 +1170,39 @@ extern "C" int cbv_pipeline_configure(cbv_pipeline* p, const cbv_pipeline_config
     for (int l = 0; l < cbv_pipeline::MAX_LANES; l++) {
         if (p->A[l]) (void)hipFree(p->A[l]);
         if (p->B[l]) (void)hipFree(p->B[l]);
-        p->A[l] = p->B[l] = nullptr;
+        if (p->C[l]) (void)hipFree(p->C[l]);
+        p->A[l] = p->B[l] = p->C[l] = nullptr;
+    }
+    // region-limited enhancement: the source footprint of the S x S warp = the image of the destination square under
+    // Minv (a projective map keeps the square convex while W > 0 on it: its four corners bound it), + 3 px for the
+    // 1/32-px rounding and the bilinear taps
+    p->use_region = false;
+    if (cfg->enhance_region && !p->keep_enhanced && sharpen_region_ok(cfg->enhance.sharpen_kernel)) {
+        double lo[2] = {1e30, 1e30}, hi[2] = {-1e30, -1e30};
+        bool ok = true;
+        for (int k = 0; k < 4 && ok; k++) {
+            const double dx = (k & 1) ? S - 1 : 0, dy = (k & 2) ? S - 1 : 0;
+            const double W = p->Minv[6] * dx + p->Minv[7] * dy + p->Minv[8];
+            if (!(W > 1e-12)) ok = false;
+            else {
+                const double c[2] = {(p->Minv[0] * dx + p->Minv[1] * dy + p->Minv[2]) / W, (p->Minv[3] * dx + p->Minv[4] * dy + p->Minv[5]) / W};
+                for (int a = 0; a < 2; a++) {
+                    lo[a] = std::min(lo[a], c[a]);
+                    hi[a] = std::max(hi[a], c[a]);
+                }
+            }
+        }
+        if (ok && hi[0] - lo[0] < 1e6 && hi[1] - lo[1] < 1e6) {
+            PxRect r = {(int)floor(lo[0]) - 3, (int)floor(lo[1]) - 3, (int)ceil(hi[0]) + 4, (int)ceil(hi[1]) + 4};
+            r.x0 = std::max(r.x0, 0);
+            r.y0 = std::max(r.y0, 0);
+            r.x1 = std::min(r.x1, p->w);
+            r.y1 = std::min(r.y1, p->h);
+            if (r.x1 > r.x0 && r.y1 > r.y0) {
+                p->region = r;
+                p->use_region = true;
+            }
+        }
     }
     if (p->warped) (void)hipFree(p->warped);
     if (p->enhanced) (void)hipFree(p->enhanced);
@@ -1140,6 +1211,7 @@ extern "C" int cbv_pipeline_configure(cbv_pipeline* p, const cbv_pipeline_config
     for (int l = 0; l < lanes; l++) {
         CBV_HIP(ctx, hipMalloc((void**)&p->A[l], p->g.frame_stride * chunk + 256));
         CBV_HIP(ctx, hipMalloc((void**)&p->B[l], p->g.frame_stride * chunk + 256));
+        if (p->use_region) CBV_HIP(ctx, hipMalloc((void**)&p->C[l], p->g.frame_stride * chunk + 256));
         SmallLayout SL;
         RC(small_layout(ctx, &p->lane_small[l], cfg->enhance.tiles_x * cfg->enhance.tiles_y, chunk, &SL, cfg->enhance.tiles_x, cfg->enhance.tiles_y));
         RC(dev_ensure(ctx, &p->lane_work[l], sizeof(u32) * (1 + (size_t)CBV_MAX_SQUARES * chunk)));
@@ -1398,7 +1470,8 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
         const int b = std::min(p->chunk, slot0 + count - s0);
         const u8* src = p->frames + p->g.frame_stride * s0;
         u8* res = nullptr;
-        rc_all = enhance_dev(ctx, src, p->A[lane], p->B[lane], p->g, &cfg.enhance, SL, b, !p->keep_enhanced, &res);
+        rc_all = enhance_dev(ctx, src, p->A[lane], p->B[lane], p->g, &cfg.enhance, SL, b, !p->keep_enhanced, &res,
+                             p->use_region ? &p->region : nullptr, p->C[lane]);
         if (rc_all) break;
         u8* wdst = p->warped + p->warped_stride * s0;
         u32* work = cfg.use_hough ? (u32*)p->lane_work[lane].p : nullptr; // worklist counter: zeroed by k_warp

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -152,6 +153,93 @@ struct Geom {
     size_t frame_stride; // bytes between consecutive frames of a batch
 };
 
+// ---------------------------------------------------------------------------
+// Region-limited enhancement (cbv_pipeline_config::enhance_region).  The pipeline's only consumer of the enhanced frame
+// is the warp, which samples the board quad; CLAHE apply, the bilateral and the sharpen + min/max pass therefore first
+// run on the part of the frame the quad (+ their stencil halos) needs.  normalize needs the min / max of the WHOLE
+// sharpened frame, but bytes cannot leave [0, 255]: if the region already holds a 0 and a 255 they ARE the global
+// extremes and the rest of the frame cannot change any output.  A second pass over the complement of each kernel's
+// region follows; its workgroups leave at once for frames whose region saturated (SatGate) and do the work otherwise,
+// so results are identical to whole-frame enhancement in every case.
+// ---------------------------------------------------------------------------
+struct PxRect {
+    int x0, y0, x1, y1; // pixels [x0, x1) x [y0, y1)
+};
+
+// up to four rectangles of a kernel's own tiles (one = a region, four = its complement), enumerated as ONE index space
+struct TileSet {
+    int n;
+    int x0[4], y0[4], w[4];
+    int cum[5]; // cum[k] = tiles in the rectangles before k; cum[n] = tiles per frame
+};
+
+// (constant indices and selects only: the set lives in kernel-argument SGPRs, a dynamic index would turn every call into
+// scalar loads from the argument segment with an s_waitcnt behind them)
+__host__ __device__ static inline void tileset_at(const TileSet& T, int r, int& tx, int& ty)
+{
+    int x0 = T.x0[0], y0 = T.y0[0], w = T.w[0], c = 0;
+    if (T.n > 1 && r >= T.cum[1]) { x0 = T.x0[1]; y0 = T.y0[1]; w = T.w[1]; c = T.cum[1]; }
+    if (T.n > 2 && r >= T.cum[2]) { x0 = T.x0[2]; y0 = T.y0[2]; w = T.w[2]; c = T.cum[2]; }
+    if (T.n > 3 && r >= T.cum[3]) { x0 = T.x0[3]; y0 = T.y0[3]; w = T.w[3]; c = T.cum[3]; }
+    const int l = r - c;
+    const int row = l / w;
+    ty = y0 + row;
+    tx = x0 + (l - row * w);
+}
+
+static inline void tileset_add(TileSet& T, int x0, int y0, int x1, int y1)
+{
+    if (x1 <= x0 || y1 <= y0) return;
+    T.x0[T.n] = x0;
+    T.y0[T.n] = y0;
+    T.w[T.n] = x1 - x0;
+    T.cum[T.n + 1] = T.cum[T.n] + (x1 - x0) * (y1 - y0);
+    T.n++;
+}
+
+// tiles [x0, x1) x [y0, y1) of a txn x tyn grid, or (invert) every other tile: strips above, below, left, right
+static inline TileSet tileset_make(int txn, int tyn, int x0, int y0, int x1, int y1, bool invert)
+{
+    TileSet T;
+    memset(&T, 0, sizeof(T));
+    x0 = x0 < 0 ? 0 : x0;
+    y0 = y0 < 0 ? 0 : y0;
+    x1 = x1 > txn ? txn : x1;
+    y1 = y1 > tyn ? tyn : y1;
+    if (x1 <= x0 || y1 <= y0) x0 = x1 = y0 = y1 = 0; // empty region: its complement is everything
+    if (!invert) tileset_add(T, x0, y0, x1, y1);
+    else {
+        tileset_add(T, 0, 0, txn, y0);
+        tileset_add(T, 0, y1, txn, tyn);
+        tileset_add(T, 0, y0, x0, y1);
+        tileset_add(T, x1, y0, txn, y1);
+    }
+    if (T.n == 0) T.w[0] = 1; // no tiles: cum[0] = 0, never dereferenced with r < 0
+    return T;
+}
+
+// frames whose min / max words (aux, after the region pass of sharpen) already read 0 / 255 are skipped
+struct SatGate {
+    const u32* mm;       // min word of frame 0 (max follows), or null = no gate
+    size_t stride_words; // between frames
+};
+__device__ static inline bool sat_gate_closed(const SatGate& G, int frame)
+{
+    return G.mm && G.mm[(size_t)frame * G.stride_words] == 0u && G.mm[(size_t)frame * G.stride_words + 1] == 255u;
+}
+
+// k_sharpen_box's region: bytes [b0, b1) of the rows (multiples of 16: a lane's chunk) x rows [y0, y1) (multiples of the
+// tile height); invert = everything else
+struct ShRegion {
+    int b0, b1, y0, y1, invert;
+};
+
+struct EnhanceRegion {
+    PxRect px;   // what the consumer samples (clipped to the frame)
+    int invert;  // 0: the region pass, 1: the complement pass
+    SatGate gate;
+};
+
 struct ClaheGeom {
     int tiles_x, tiles_y, tw, th; // tile size of the (possibly extended) image
     int clip;                     // integer clip limit (0 = none)
@@ -178,10 +266,16 @@ int launch_reset_aux(cbv_ctx* ctx, u32* aux, int tiles, int batch);
 int launch_color_lab_hist(cbv_ctx* ctx, const u8* src, u8* lab, u32* aux, Geom g, ClaheGeom cg, int batch,
                           int do_profile, int do_lab);
 int launch_clahe_lut(cbv_ctx* ctx, const u32* aux, u8* luts, ClaheGeom cg, int batch, u32* packed);
-int launch_clahe_apply(cbv_ctx* ctx, const u8* lab, const u32* packed, u8* dst, Geom g, ClaheGeom cg, int batch);
+int launch_clahe_apply(cbv_ctx* ctx, const u8* lab, const u32* packed, u8* dst, Geom g, ClaheGeom cg, int batch, const EnhanceRegion* er = nullptr);
 int launch_clahe_gray(cbv_ctx* ctx, const u8* src, int w, int h, int stride, ClaheGeom cg, u32* aux, u8* luts, u8* dst);
-int launch_bilateral(cbv_ctx* ctx, const u8* src, u8* dst, Geom g, int batch);
-int launch_sharpen(cbv_ctx* ctx, const u8* src, u8* dst, u32* aux, int tiles, Geom g, const float* k9, int batch);
+int launch_bilateral(cbv_ctx* ctx, const u8* src, u8* dst, Geom g, int batch, const EnhanceRegion* er = nullptr);
+int launch_sharpen(cbv_ctx* ctx, const u8* src, u8* dst, u32* aux, int tiles, Geom g, const float* k9, int batch, const EnhanceRegion* er = nullptr);
+// pixel rectangles the region pass of a kernel covers / must find complete in its input (tile rounding, halos); `out` of
+// one stage dilated by its halo is the `need` of the stage before it
+bool sharpen_region_ok(const float* k9);
+PxRect sharpen_region_cover(Geom g, PxRect need);
+PxRect bilateral_region_cover(cbv_ctx* ctx, Geom g, int batch, PxRect need);
+PxRect clahe_region_cover(Geom g, PxRect need);
 int launch_norm_lut(cbv_ctx* ctx, const u32* aux, int tiles, u8* norm_lut, int batch);
 int launch_normalize(cbv_ctx* ctx, const u8* src, u8* dst, const u8* norm_lut, Geom g, int batch);
 int launch_warp(cbv_ctx* ctx, const u8* src, Geom g, const double* Minv9, int dw, int dh, int rot180, u8* dst,

@@ -48,8 +48,8 @@ __host__ __device__ constexpr int bl_row_reach(int R, int dy)
 // NT lanes per workgroup (a multiple of 64): 32 strips x NT / 32 row pairs, i.e. tiles of 128 x NT / 16 pixels
 template <int R, int NT>
 __global__ __launch_bounds__(NT) void k_bilateral(const u8* __restrict__ src, u8* __restrict__ dst, Geom g,
-                                                           const BilateralTabs* __restrict__ bt, int tiles_xn,
-                                                           int tiles_yn, int batch)
+                                                           const BilateralTabs* __restrict__ bt, TileSet ts, int batch,
+                                                           SatGate gate)
 {
     // static LDS (69 KB): compile-time addresses let the table gather use the ds_read immediate offset
     __shared__ __attribute__((aligned(16))) float fw[BL_LUT_WORDS];              // [class][768] folded weights
@@ -63,21 +63,32 @@ __global__ __launch_bounds__(NT) void k_bilateral(const u8* __restrict__ src, u8
     const int tid = threadIdx.x;
     for (int i = tid; i < bt->ncls * 768; i += BL_THREADS) fw[i] = (&bt->folded[0][0])[i];
 
-    const int tiles_per_frame = tiles_xn * tiles_yn;
+    const int tiles_per_frame = ts.cum[ts.n]; // the tiles of this launch's region (TileSet), not of the whole frame
     const int ntiles = tiles_per_frame * batch;
     const bool aligned = (g.stride & 3) == 0;
 
     // Interior 4-pixel groups are prefetched as 3 raw dwords; groups that touch the image border
     // (REFLECT_101) are rare and are fetched synchronously, byte-wise, when the tile is written.
-    auto group_origin = [&](int t, int gi, int& f, int& y, int& gx) {
-        f = t / tiles_per_frame;
-        const int tt = t - f * tiles_per_frame;
-        const int tyi = tt / tiles_xn, txi = tt - tyi * tiles_xn;
-        const int r = gi / GROUPS, gc = gi - r * GROUPS;
-        y = tyi * BL_TH - R + r;
-        gx = txi * BL_TW - BL_HALO + gc * 4;
+    // a tile: frame and pixel origin (wave-uniform; worked out once per tile)
+    struct TileAt {
+        int f, px0, py0;
     };
-    auto prefetch = [&](int t, int gi, u32* d) {
+    auto tile_at = [&](int t) {
+        TileAt a;
+        a.f = t / tiles_per_frame;
+        int tyi, txi;
+        tileset_at(ts, t - a.f * tiles_per_frame, txi, tyi);
+        a.px0 = txi * BL_TW;
+        a.py0 = tyi * BL_TH;
+        return a;
+    };
+    auto group_origin = [&](const TileAt& ta, int gi, int& f, int& y, int& gx) {
+        f = ta.f;
+        const int r = gi / GROUPS, gc = gi - r * GROUPS;
+        y = ta.py0 - R + r;
+        gx = ta.px0 - BL_HALO + gc * 4;
+    };
+    auto prefetch = [&](const TileAt& t, int gi, u32* d) {
         int f, y, gx;
         group_origin(t, gi, f, y, gx);
         if (aligned && gx >= 0 && gx + 3 < g.w && y >= 0 && y < g.h) {
@@ -87,7 +98,7 @@ __global__ __launch_bounds__(NT) void k_bilateral(const u8* __restrict__ src, u8
             d[2] = q[2];
         }
     };
-    auto commit = [&](int t, int gi, const u32* d) {
+    auto commit = [&](const TileAt& t, int gi, const u32* d) {
         int f, y, gx;
         group_origin(t, gi, f, y, gx);
         u32 p0, p1, p2, p3;
@@ -113,37 +124,43 @@ __global__ __launch_bounds__(NT) void k_bilateral(const u8* __restrict__ src, u8
         *(uint4*)&tile[r * BL_PITCH + gc * 4] = make_uint4(p0, p1, p2, p3);
     };
 
-    // persistent walk: sequence number s = i * gridDim + block; XCD x owns a contiguous tile range
-    int s = blockIdx.x;
+    // persistent walk: sequence number s = i * gridDim + block; XCD x owns a contiguous tile range.  Tiles of frames
+    // whose gate is closed (complement pass of a frame whose region already holds 0 and 255) are stepped over.
+    auto next_open = [&](int s) {
+        while (s < ntiles && sat_gate_closed(gate, xcd_remap(s, ntiles) / tiles_per_frame)) s += gridDim.x;
+        return s;
+    };
+    int s = next_open(blockIdx.x);
     u32 pre[GPT][3];
+    TileAt cur = {0, 0, 0};
     if (s < ntiles) {
-        const int t = xcd_remap(s, ntiles);
+        cur = tile_at(xcd_remap(s, ntiles));
 #pragma unroll
         for (int k = 0; k < GPT; k++) {
             const int gi = tid + k * BL_THREADS;
-            if (gi < NG) prefetch(t, gi, pre[k]);
+            if (gi < NG) prefetch(cur, gi, pre[k]);
         }
     }
     const int sx = tid & 31;  // strip: pixels 4*sx .. 4*sx+3
     const int ly = (tid >> 5) * 2; // first of the lane's two tile rows
 
-    for (; s < ntiles; s += gridDim.x) {
-        const int t = xcd_remap(s, ntiles);
+    while (s < ntiles) {
+        const TileAt here = cur;
         __syncthreads(); // previous tile fully consumed (and the LUT is written on the first pass)
 #pragma unroll
         for (int k = 0; k < GPT; k++) {
             const int gi = tid + k * BL_THREADS;
-            if (gi < NG) commit(t, gi, pre[k]);
+            if (gi < NG) commit(here, gi, pre[k]);
         }
         __syncthreads();
         // prefetch the next tile while this one is filtered
-        const int sn = s + gridDim.x;
-        if (sn < ntiles) {
-            const int tn = xcd_remap(sn, ntiles);
+        s = next_open(s + gridDim.x);
+        if (s < ntiles) {
+            cur = tile_at(xcd_remap(s, ntiles));
 #pragma unroll
             for (int k = 0; k < GPT; k++) {
                 const int gi = tid + k * BL_THREADS;
-                if (gi < NG) prefetch(tn, gi, pre[k]);
+                if (gi < NG) prefetch(cur, gi, pre[k]);
             }
         }
 
@@ -204,12 +221,11 @@ __global__ __launch_bounds__(NT) void k_bilateral(const u8* __restrict__ src, u8
                 }
             }
         }
-        const int f = t / tiles_per_frame, tt = t - f * tiles_per_frame;
-        const int tyi = tt / tiles_xn, txi = tt - tyi * tiles_xn;
-        const int x = txi * BL_TW + sx * 4;
+        const int f = here.f;
+        const int x = here.px0 + sx * 4;
 #pragma unroll
         for (int a = 0; a < 2; a++) {
-            const int y = tyi * BL_TH + ly + a;
+            const int y = here.py0 + ly + a;
             if (y < g.h && x < g.w) {
                 Px4 out;
                 out.d[0] = out.d[1] = out.d[2] = 0;
@@ -238,47 +254,68 @@ __global__ __launch_bounds__(NT) void k_bilateral(const u8* __restrict__ src, u8
     }
 }
 
-template <int R, int NT>
-static int launch_bilateral_r(cbv_ctx* ctx, const u8* src, u8* dst, Geom g, int batch, int wgs_per_cu)
+// NT and workgroups per CU for a launch: 768 lanes = 3 waves per SIMD at <= 128 VGPRs: alone the kernel is 11 % slower
+// than with 1024 lanes (4 waves hide the LDS gather better), but a fourth wave slot and 160 VGPRs per SIMD stay free, so
+// the other lane's kernels run BESIDE it instead of waiting for its persistent workgroups to end; the whole path gains
+// 2-3 % (gpurun sweep, 1080p x 512: 640 lanes 26.0 k frames/s, 768 27.8 k, 896 25.5 k, 1024 27.2 k, 2 x 512 25.9 k).
+// One or two frames (the live-camera case) are too few 128 x 48 tiles for 256 persistent workgroups (a 1080p frame has
+// 345: the second round is a third full).  128 x 32 tiles on TWO 512-lane workgroups per CU (2 x 52 KB of LDS, the same
+// 4 waves per SIMD as one 1024-lane workgroup) put 510 tiles on 512 workgroups in one round.
+static int bilateral_nt(cbv_ctx* ctx, Geom g, int batch)
 {
-    constexpr int TH = NT / 16;
-    const int txn = (g.w + BL_TW - 1) / BL_TW, tyn = (g.h + TH - 1) / TH;
-    const int ntiles = txn * tyn * batch;
-    int grid = ctx->num_cus * wgs_per_cu < ntiles ? ctx->num_cus * wgs_per_cu : ntiles; // persistent workgroups
-    grid = (grid + 7) & ~7;                                   // whole XCD groups
+    const long long t768 = (long long)((g.w + BL_TW - 1) / BL_TW) * ((g.h + 768 / 16 - 1) / (768 / 16)) * batch;
+    return t768 < 2ll * ctx->num_cus ? 512 : 768;
+}
+
+// tiles of the launch: the whole frame, or (region-limited enhancement) the tiles covering er->px / all the others
+static TileSet bilateral_tiles(Geom g, int nt, const EnhanceRegion* er)
+{
+    const int th = nt / 16;
+    const int txn = (g.w + BL_TW - 1) / BL_TW, tyn = (g.h + th - 1) / th;
+    if (!er) return tileset_make(txn, tyn, 0, 0, txn, tyn, false);
+    return tileset_make(txn, tyn, er->px.x0 / BL_TW, er->px.y0 / th, (er->px.x1 + BL_TW - 1) / BL_TW, (er->px.y1 + th - 1) / th, er->invert != 0);
+}
+
+PxRect bilateral_region_cover(cbv_ctx* ctx, Geom g, int batch, PxRect need)
+{
+    const int th = bilateral_nt(ctx, g, batch) / 16;
+    PxRect c = {need.x0 / BL_TW * BL_TW, need.y0 / th * th, (need.x1 + BL_TW - 1) / BL_TW * BL_TW, (need.y1 + th - 1) / th * th};
+    c.x1 = c.x1 > g.w ? g.w : c.x1;
+    c.y1 = c.y1 > g.h ? g.h : c.y1;
+    return c;
+}
+
+template <int R, int NT>
+static int launch_bilateral_r(cbv_ctx* ctx, const u8* src, u8* dst, Geom g, int batch, int wgs_per_cu, const EnhanceRegion* er)
+{
+    const TileSet ts = bilateral_tiles(g, NT, er);
+    const long long ntiles = (long long)ts.cum[ts.n] * batch;
+    if (ntiles == 0) return CBV_OK;
+    long long grid = (long long)ctx->num_cus * wgs_per_cu < ntiles ? (long long)ctx->num_cus * wgs_per_cu : ntiles; // persistent workgroups
+    grid = (grid + 7) & ~7ll;                                 // whole XCD groups
     if (grid > ntiles) grid = ntiles;
+    const SatGate gate = er ? er->gate : SatGate{nullptr, 0};
     prof_begin(ctx, CBV_K_BILATERAL);
-    hipLaunchKernelGGL((k_bilateral<R, NT>), dim3(grid), dim3(NT), 0, ctx->stream, src, dst, g, ctx->btabs, txn, tyn, batch);
+    hipLaunchKernelGGL((k_bilateral<R, NT>), dim3((unsigned)grid), dim3(NT), 0, ctx->stream, src, dst, g, ctx->btabs, ts, batch, gate);
     prof_end(ctx, CBV_K_BILATERAL);
     CBV_HIP(ctx, hipGetLastError());
     return CBV_OK;
 }
 
-int launch_bilateral(cbv_ctx* ctx, const u8* src, u8* dst, Geom g, int batch)
+int launch_bilateral(cbv_ctx* ctx, const u8* src, u8* dst, Geom g, int batch, const EnhanceRegion* er)
 {
-    // 768 lanes = 3 waves per SIMD at <= 128 VGPRs: alone the kernel is 11 % slower than with 1024 lanes (4 waves hide
-    // the LDS gather better), but a fourth wave slot and 160 VGPRs per SIMD stay free, so the other lane's kernels run
-    // BESIDE it instead of waiting for its persistent workgroups to end; the whole path gains 2-3 %
-    // (gpurun sweep, 1080p x 512: 640 lanes 26.0 k frames/s, 768 27.8 k, 896 25.5 k, 1024 27.2 k, 2 x 512 25.9 k).
-    constexpr int NT = 768;
-    // One or two frames (the live-camera case) are too few 128 x 48 tiles for 256 persistent workgroups (a 1080p frame has
-    // 345: the second round is a third full).  128 x 32 tiles on TWO 512-lane workgroups per CU (2 x 52 KB of LDS, the
-    // same 4 waves per SIMD as one 1024-lane workgroup) put 510 tiles on 512 workgroups in one round.
-    {
-        const long long t768 = (long long)((g.w + BL_TW - 1) / BL_TW) * ((g.h + NT / 16 - 1) / (NT / 16)) * batch;
-        if (t768 < 2ll * ctx->num_cus) switch (ctx->btabs_host.radius) {
-            case 1: return launch_bilateral_r<1, 512>(ctx, src, dst, g, batch, 2);
-            case 2: return launch_bilateral_r<2, 512>(ctx, src, dst, g, batch, 2);
-            case 3: return launch_bilateral_r<3, 512>(ctx, src, dst, g, batch, 2);
-            case 4: return launch_bilateral_r<4, 512>(ctx, src, dst, g, batch, 2);
-            default: break;
-            }
-    }
-    switch (ctx->btabs_host.radius) {
-    case 1: return launch_bilateral_r<1, NT>(ctx, src, dst, g, batch, 1);
-    case 2: return launch_bilateral_r<2, NT>(ctx, src, dst, g, batch, 1);
-    case 3: return launch_bilateral_r<3, NT>(ctx, src, dst, g, batch, 1);
-    case 4: return launch_bilateral_r<4, NT>(ctx, src, dst, g, batch, 1);
-    default: return cbv_fail(ctx, CBV_ERR_UNSUPPORTED, "bilateral radius %d not supported (d <= 9)", ctx->btabs_host.radius);
+    const int R = ctx->btabs_host.radius;
+    if (R < 1 || R > 4) return cbv_fail(ctx, CBV_ERR_UNSUPPORTED, "bilateral radius %d not supported (d <= 9)", R);
+    if (bilateral_nt(ctx, g, batch) == 512) switch (R) {
+        case 1: return launch_bilateral_r<1, 512>(ctx, src, dst, g, batch, 2, er);
+        case 2: return launch_bilateral_r<2, 512>(ctx, src, dst, g, batch, 2, er);
+        case 3: return launch_bilateral_r<3, 512>(ctx, src, dst, g, batch, 2, er);
+        default: return launch_bilateral_r<4, 512>(ctx, src, dst, g, batch, 2, er);
+        }
+    switch (R) {
+    case 1: return launch_bilateral_r<1, 768>(ctx, src, dst, g, batch, 1, er);
+    case 2: return launch_bilateral_r<2, 768>(ctx, src, dst, g, batch, 1, er);
+    case 3: return launch_bilateral_r<3, 768>(ctx, src, dst, g, batch, 1, er);
+    default: return launch_bilateral_r<4, 768>(ctx, src, dst, g, batch, 1, er);
     }
 }

@@ -312,11 +312,16 @@ __device__ __forceinline__ int d_ab_to_xz(int i)
 }
 
 #define CLAHE_MAX_TILES_X 32
+// RG = false: the whole-frame launch, with the region code compiled out
+template <bool RG>
 __global__ __launch_bounds__(256) void k_clahe_apply(const u8* __restrict__ lab, const u32* __restrict__ packed,
                                                       u8* __restrict__ dst, Geom g, ClaheGeom cg,
                                                       const StaticTabs* __restrict__ st, int rows_per_wg,
-                                                      int tiles_total)
+                                                      int tiles_total, PxRect cov, int invert, SatGate gate)
 {
+    // region-limited enhancement: only the pixels of `cov` (x in 4-pixel groups), or (invert) all the others, and in
+    // that complement pass nothing for frames whose region already holds 0 and 255 (cbv_internal.h)
+    if (RG && sat_gate_closed(gate, blockIdx.z)) return;
     // static LDS: table addresses become ds_read immediates (no per-lookup base add)
     __shared__ u16 inv_gamma[INV_GAMMA_TAB_SIZE];
     __shared__ u32 lab_yf[256];          // y | ify << 16: one gather for the pair
@@ -341,6 +346,8 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const u8* __restrict__ lab,
     const int y0 = yb0 + blockIdx.x * rows_per_wg;
     if (y0 >= yb1) return;
     const int y1 = min(y0 + rows_per_wg, yb1);
+    if (RG && !invert && (y1 <= cov.y0 || y0 >= cov.y1)) return; // none of this workgroup's rows is in the region
+    const int gx0 = cov.x0 >> 2, gx1 = (cov.x1 + 3) >> 2;
 
     lds_copy(inv_gamma, st->inv_gamma, INV_GAMMA_TAB_SIZE * 2);
     lds_copy(lab_yf, st->lab_yf, 1024); // u16 pairs (y, ify) read back as one word
@@ -356,87 +363,128 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const u8* __restrict__ lab,
     const int groups = (g.w + 3) >> 2;
     const int shift = LAB_SHIFT + (LAB_BASE_SHIFT - INV_GAMMA_SHIFT);
 
-    // a lane keeps its 4-pixel column group and walks the chunk's rows: the x interpolation
-    // parameters (tile pair, xa) are computed once per group instead of once per pixel
-    for (int gi = threadIdx.x; gi < groups; gi += blockDim.x) {
-        const int x0 = gi * 4;
-        const int npx = min(4, g.w - x0);
-        const bool fast = aligned && npx == 4;
-        int op[4]; // byte offset of the pixel's column pair in pk
-        float xa[4], xa1[4];
+    // x interpolation parameters of a 4-pixel column group (tile pair, xa)
+    auto xparam = [&](int gi, int (&op)[4], float (&xa)[4], float (&xa1)[4]) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const float txf = (float)(x0 + k) * inv_tw - 0.5f;
+            const float txf = (float)(gi * 4 + k) * inv_tw - 0.5f;
             int tx1 = d_floor_f(txf);
             xa[k] = txf - (float)tx1;
             xa1[k] = 1.0f - xa[k];
-            op[k] = min(max(tx1 + 1, 0), cg.tiles_x) * 1024;
+            op[k] = min(max(tx1 + 1, 0), cg.tiles_x) * 1024; // byte offset of the pixel's column pair in pk
         }
-        for (int y = y0; y < y1; y++) {
-            const float tyf = (float)y * inv_th - 0.5f;
-            const float ya = tyf - (float)d_floor_f(tyf), ya1 = 1.0f - ya;
-            Px4 px;
-            u32 P[4] = {0, 0, 0, 0};
-            const u8* p = sf + (size_t)y * g.stride + (size_t)x0 * 3;
-            if (fast) {
-                const u32* pw = (const u32*)p;
-                px.d[0] = pw[0];
-                px.d[1] = pw[1];
-                px.d[2] = pw[2];
-            } else {
-                px.d[0] = px.d[1] = px.d[2] = 0;
+    };
+    // one group of one row
+    auto do_row = [&](int gi, int y, const int (&op)[4], const float (&xa)[4], const float (&xa1)[4]) {
+        const int x0 = gi * 4;
+        const int npx = min(4, g.w - x0);
+        const bool fast = aligned && npx == 4;
+        const float tyf = (float)y * inv_th - 0.5f;
+        const float ya = tyf - (float)d_floor_f(tyf), ya1 = 1.0f - ya;
+        Px4 px;
+        u32 P[4] = {0, 0, 0, 0};
+        const u8* p = sf + (size_t)y * g.stride + (size_t)x0 * 3;
+        if (fast) {
+            const u32* pw = (const u32*)p;
+            px.d[0] = pw[0];
+            px.d[1] = pw[1];
+            px.d[2] = pw[2];
+        } else {
+            px.d[0] = px.d[1] = px.d[2] = 0;
 #pragma unroll
-                for (int k = 0; k < 12; k++)
-                    if (k < npx * 3) px_set(px, k, p[k]);
+            for (int k = 0; k < 12; k++)
+                if (k < npx * 3) px_set(px, k, p[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (k < npx) {
+                const int v = px_get(px, 3 * k);
+                const u32 cw = *(const u32*)((const u8*)pk + op[k] + v * 4); // the four corner LUT values of L = v
+                float ra = (float)(cw & 255u) * xa1[k] + (float)((cw >> 8) & 255u) * xa[k];
+                float rb = (float)((cw >> 16) & 255u) * xa1[k] + (float)(cw >> 24) * xa[k];
+                float res = ra * ya1 + rb * ya;
+                const int LL = (int)__builtin_amdgcn_cvt_pk_u8_f32(res, 0, 0u); // round-half-even + saturate
+                // Lab2RGBinteger
+                const int aa = px_get(px, 3 * k + 1), bb = px_get(px, 3 * k + 2);
+                const u32 yf = lab_yf[LL];
+                const int yv = (int)(yf & 0xFFFFu), ify = (int)(yf >> 16);
+                const int adiv = ((5 * aa * 53687 + (1 << 7)) >> 13) - 128 * LAB_BASE / 500;
+                const int bdiv = ((bb * 41943 + (1 << 4)) >> 9) - 128 * LAB_BASE / 200 + 1;
+                const int xv = d_ab_to_xz(ify + adiv), zv = d_ab_to_xz(ify - bdiv);
+                // |x|,|y|,|z| < 2^17 and |coefficient| < 2^14: 24-bit multiplies are exact
+                int ro = D_DESCALE(__mul24(invc[0], xv) + __mul24(invc[1], yv) + __mul24(invc[2], zv), shift);
+                int go = D_DESCALE(__mul24(invc[3], xv) + __mul24(invc[4], yv) + __mul24(invc[5], zv), shift);
+                int bo = D_DESCALE(__mul24(invc[6], xv) + __mul24(invc[7], yv) + __mul24(invc[8], zv), shift);
+                ro = min(max(ro, 0), INV_GAMMA_TAB_SIZE - 1);
+                go = min(max(go, 0), INV_GAMMA_TAB_SIZE - 1);
+                bo = min(max(bo, 0), INV_GAMMA_TAB_SIZE - 1);
+                // table entries are <= 255 by construction: saturate_cast is the identity
+                P[k] = d_pack3(inv_gamma[bo], inv_gamma[go], inv_gamma[ro]);
             }
+        }
+        u8* q = df + (size_t)y * g.stride + (size_t)x0 * 3;
+        if (fast) {
+            u32* qw = (u32*)q;
+            qw[0] = __builtin_amdgcn_perm(P[1], P[0], 0x04020100u);
+            qw[1] = __builtin_amdgcn_perm(P[2], P[1], 0x05040201u);
+            qw[2] = __builtin_amdgcn_perm(P[3], P[2], 0x06050402u);
+        } else {
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < 4; k++)
                 if (k < npx) {
-                    const int v = px_get(px, 3 * k);
-                    const u32 cw = *(const u32*)((const u8*)pk + op[k] + v * 4); // the four corner LUT values of L = v
-                    float ra = (float)(cw & 255u) * xa1[k] + (float)((cw >> 8) & 255u) * xa[k];
-                    float rb = (float)((cw >> 16) & 255u) * xa1[k] + (float)(cw >> 24) * xa[k];
-                    float res = ra * ya1 + rb * ya;
-                    const int LL = (int)__builtin_amdgcn_cvt_pk_u8_f32(res, 0, 0u); // round-half-even + saturate
-                    // Lab2RGBinteger
-                    const int aa = px_get(px, 3 * k + 1), bb = px_get(px, 3 * k + 2);
-                    const u32 yf = lab_yf[LL];
-                    const int yv = (int)(yf & 0xFFFFu), ify = (int)(yf >> 16);
-                    const int adiv = ((5 * aa * 53687 + (1 << 7)) >> 13) - 128 * LAB_BASE / 500;
-                    const int bdiv = ((bb * 41943 + (1 << 4)) >> 9) - 128 * LAB_BASE / 200 + 1;
-                    const int xv = d_ab_to_xz(ify + adiv), zv = d_ab_to_xz(ify - bdiv);
-                    // |x|,|y|,|z| < 2^17 and |coefficient| < 2^14: 24-bit multiplies are exact
-                    int ro = D_DESCALE(__mul24(invc[0], xv) + __mul24(invc[1], yv) + __mul24(invc[2], zv), shift);
-                    int go = D_DESCALE(__mul24(invc[3], xv) + __mul24(invc[4], yv) + __mul24(invc[5], zv), shift);
-                    int bo = D_DESCALE(__mul24(invc[6], xv) + __mul24(invc[7], yv) + __mul24(invc[8], zv), shift);
-                    ro = min(max(ro, 0), INV_GAMMA_TAB_SIZE - 1);
-                    go = min(max(go, 0), INV_GAMMA_TAB_SIZE - 1);
-                    bo = min(max(bo, 0), INV_GAMMA_TAB_SIZE - 1);
-                    // table entries are <= 255 by construction: saturate_cast is the identity
-                    P[k] = d_pack3(inv_gamma[bo], inv_gamma[go], inv_gamma[ro]);
+                    q[3 * k] = (u8)(P[k] & 255);
+                    q[3 * k + 1] = (u8)((P[k] >> 8) & 255);
+                    q[3 * k + 2] = (u8)((P[k] >> 16) & 255);
                 }
-            }
-            u8* q = df + (size_t)y * g.stride + (size_t)x0 * 3;
-            if (fast) {
-                u32* qw = (u32*)q;
-                qw[0] = __builtin_amdgcn_perm(P[1], P[0], 0x04020100u);
-                qw[1] = __builtin_amdgcn_perm(P[2], P[1], 0x05040201u);
-                qw[2] = __builtin_amdgcn_perm(P[3], P[2], 0x06050402u);
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (k < npx) {
-                        q[3 * k] = (u8)(P[k] & 255);
-                        q[3 * k + 1] = (u8)((P[k] >> 8) & 255);
-                        q[3 * k + 2] = (u8)((P[k] >> 16) & 255);
-                    }
-            }
+        }
+    };
+    if (RG && !invert && (gx0 > 0 || gx1 < groups)) {
+        // region pass on a part of the columns: (row, group) items dealt out over the lanes, so that no lane idles on
+        // the columns outside the region (x parameters per item: ~10 of its ~370 instructions)
+        const int c0 = min(gx0, groups), ngr = min(gx1, groups) - c0;
+        const int r0 = max(y0, cov.y0), nr = min(y1, cov.y1) - r0;
+        for (int item = threadIdx.x; item < ngr * nr; item += blockDim.x) {
+            const int ry = item / ngr, gi = c0 + (item - ry * ngr);
+            int op[4];
+            float xa[4], xa1[4];
+            xparam(gi, op, xa, xa1);
+            do_row(gi, r0 + ry, op, xa, xa1);
+        }
+        return;
+    }
+    // a lane keeps its 4-pixel column group and walks the chunk's rows: the x interpolation
+    // parameters are computed once per group instead of once per pixel
+    for (int gi = threadIdx.x; gi < groups; gi += blockDim.x) {
+        const bool col_in = gi >= gx0 && gi < gx1;
+        if (RG && !invert && !col_in) continue;
+        int op[4];
+        float xa[4], xa1[4];
+        xparam(gi, op, xa, xa1);
+        for (int y = y0; y < y1; y++) {
+            const bool row_in = y >= cov.y0 && y < cov.y1;
+            if (RG && (invert ? (row_in && col_in) : !row_in)) continue;
+            do_row(gi, y, op, xa, xa1);
         }
     }
 }
 
-int launch_clahe_apply(cbv_ctx* ctx, const u8* lab, const u32* packed, u8* dst, Geom g, ClaheGeom cg, int batch)
+PxRect clahe_region_cover(Geom g, PxRect need)
 {
+    PxRect c = {need.x0 & ~3, need.y0, (need.x1 + 3) & ~3, need.y1};
+    c.x1 = c.x1 > g.w ? g.w : c.x1;
+    return c;
+}
+
+int launch_clahe_apply(cbv_ctx* ctx, const u8* lab, const u32* packed, u8* dst, Geom g, ClaheGeom cg, int batch, const EnhanceRegion* er)
+{
+    PxRect cov = {0, 0, g.w, g.h};
+    int invert = 0;
+    SatGate gate = {nullptr, 0};
+    if (er) {
+        cov = clahe_region_cover(g, er->px);
+        invert = er->invert;
+        gate = er->gate;
+    }
     // 8 rows per workgroup amortise the 18 KB of tables it stages; a launch of one or two frames (the live-camera
     // case) would then put only ~150 workgroups on 256 CUs, so small batches take fewer rows, down to one
     int rows_per_wg = 8;
@@ -446,8 +494,12 @@ int launch_clahe_apply(cbv_ctx* ctx, const u8* lab, const u32* packed, u8* dst, 
     // a band is at most th rows (+1 for rounding)
     dim3 grid((cg.th + 1 + rows_per_wg - 1) / rows_per_wg, cg.tiles_y + 1, batch);
     prof_begin(ctx, CBV_K_CLAHE_APPLY);
-    hipLaunchKernelGGL(k_clahe_apply, grid, dim3(256), (size_t)(cg.tiles_x + 1) * 1024, ctx->stream, lab, packed, dst, g, cg, ctx->tabs,
-                       rows_per_wg, tiles);
+    if (er)
+        hipLaunchKernelGGL(k_clahe_apply<true>, grid, dim3(256), (size_t)(cg.tiles_x + 1) * 1024, ctx->stream, lab, packed, dst, g, cg, ctx->tabs,
+                           rows_per_wg, tiles, cov, invert, gate);
+    else
+        hipLaunchKernelGGL(k_clahe_apply<false>, grid, dim3(256), (size_t)(cg.tiles_x + 1) * 1024, ctx->stream, lab, packed, dst, g, cg, ctx->tabs,
+                           rows_per_wg, tiles, cov, invert, gate);
     prof_end(ctx, CBV_K_CLAHE_APPLY);
     CBV_HIP(ctx, hipGetLastError());
     return CBV_OK;
@@ -610,16 +662,17 @@ typedef short shb_s2 __attribute__((ext_vector_type(2)));
 template <bool PACKED>
 __global__ __launch_bounds__(256) void k_sharpen_box(const u8* __restrict__ src, u8* __restrict__ dst,
                                                       u32* __restrict__ aux, int tiles_total, Geom g, float a, float ca,
-                                                      int tiles_xn, int tiles_n)
+                                                      TileSet ts, SatGate gate, ShRegion rg)
 {
+    if (sat_gate_closed(gate, blockIdx.z)) return; // complement pass of a frame whose region already holds 0 and 255
     __shared__ __attribute__((aligned(16))) u8 tile[(SHB_TH + 2) * SHB_PITCH];
     __shared__ int red[8];
 #ifdef SH_TIMING
     unsigned long long sh_t[4] = {0, 0, 0, 0};
 #endif
     SH_STAMP(0);
-    const int tid = xcd_remap(blockIdx.x, tiles_n);
-    const int tyi = tid / tiles_xn, txi = tid - tyi * tiles_xn;
+    int tyi, txi;
+    tileset_at(ts, xcd_remap(blockIdx.x, ts.cum[ts.n]), txi, tyi);
     const int xb0 = txi * SHB_TB, y0 = tyi * SHB_TH;
     const size_t fo = (size_t)blockIdx.z * g.frame_stride;
     const u8* sf = src + fo;
@@ -695,7 +748,11 @@ __global__ __launch_bounds__(256) void k_sharpen_box(const u8* __restrict__ src,
     const int lc = threadIdx.x & 63, rq = threadIdx.x >> 6; // 64 chunks of 16 B x 4 row quads
     const int x0 = xb0 + lc * 16;
     int imin = 255, imax = 0;
-    if (PACKED && x0 < wb) {
+    // region-limited launches cut tiles at 16-byte chunks: a lane produces its chunk (store, min / max) only when the
+    // chunk is inside the launch's region (rows are cut at tile boundaries); the whole-frame launch has everything inside
+    const bool in_rg = y0 >= rg.y0 && y0 < rg.y1 && x0 >= rg.b0 && x0 < rg.b1;
+    const bool mine = rg.invert ? !in_rg : in_rg;
+    if (PACKED && x0 < wb && mine) {
         const int nbytes = min(16, wb - x0);
         // wave-uniform (a scalar branch, not per-lane selects): every lane of the wave owns 16 output bytes; false only
         // for the wave that holds the row's last chunk
@@ -774,7 +831,7 @@ __global__ __launch_bounds__(256) void k_sharpen_box(const u8* __restrict__ src,
             imax = min(max((int)max(vmax.x, vmax.y), 0), 255);
         }
     }
-    if (!PACKED && x0 < wb) {
+    if (!PACKED && x0 < wb && mine) {
         const int nbytes = min(16, wb - x0);
         float h[3][16]; // horizontal 3-sums of the last three staged rows
         float c[2][16]; // centre values of the last two staged rows
@@ -876,24 +933,66 @@ extern "C" __attribute__((visibility("default"))) int cbv_debug_sharpen_stamps(u
 }
 #endif
 
-int launch_sharpen(cbv_ctx* ctx, const u8* src, u8* dst, u32* aux, int tiles, Geom g, const float* k, int batch)
+// a * box + (c - a) * centre with small integers?  (Only that form has a region-limited launch.)
+bool sharpen_region_ok(const float* k)
 {
-    // a * box + (c - a) * centre with small integers?
     const float a = k[0], c = k[4];
-    bool box = true;
     for (int i = 0; i < 9; i++)
-        if (i != 4 && k[i] != a) box = false;
-    if (a != (float)(int)a || c != (float)(int)c || fabsf(a) > 64.f || fabsf(c) > 64.f) box = false;
+        if (i != 4 && k[i] != a) return false;
+    return !(a != (float)(int)a || c != (float)(int)c || fabsf(a) > 64.f || fabsf(c) > 64.f);
+}
+
+// the box kernel's region for the pixels of `need`: bytes cut at 16-byte chunks (a lane's unit), rows at tile rows
+static ShRegion sharpen_region(PxRect need, int invert)
+{
+    ShRegion r;
+    r.b0 = need.x0 * 3 / 16 * 16;
+    r.b1 = (need.x1 * 3 + 15) / 16 * 16;
+    r.y0 = need.y0 / SHB_TH * SHB_TH;
+    r.y1 = (need.y1 + SHB_TH - 1) / SHB_TH * SHB_TH;
+    r.invert = invert;
+    return r;
+}
+
+PxRect sharpen_region_cover(Geom g, PxRect need)
+{
+    const ShRegion r = sharpen_region(need, 0);
+    // whole pixels the chunks touch (a pixel cut by a chunk edge is written by both neighbours)
+    PxRect c = {r.b0 / 3, r.y0, (r.b1 + 2) / 3, r.y1};
+    c.x1 = c.x1 > g.w ? g.w : c.x1;
+    c.y1 = c.y1 > g.h ? g.h : c.y1;
+    return c;
+}
+
+int launch_sharpen(cbv_ctx* ctx, const u8* src, u8* dst, u32* aux, int tiles, Geom g, const float* k, int batch, const EnhanceRegion* er)
+{
+    const float a = k[0], c = k[4];
+    const bool box = sharpen_region_ok(k);
+    if (er && !box) return cbv_fail(ctx, CBV_ERR_STATE, "launch_sharpen: region-limited launch of a kernel that is not box-shaped");
     prof_begin(ctx, CBV_K_SHARPEN);
     if (box) {
         const int txn = (g.w * 3 + SHB_TB - 1) / SHB_TB, tyn = (g.h + SHB_TH - 1) / SHB_TH;
+        TileSet ts = tileset_make(txn, tyn, 0, 0, txn, tyn, false);
+        SatGate gate = {nullptr, 0};
+        ShRegion rg = {0, 0x7fffffff, 0, 0x7fffffff, 0};
+        if (er) {
+            rg = sharpen_region(er->px, er->invert);
+            // region pass: every tile the region touches; complement pass: every tile not wholly inside it (the tiles
+            // the region's left and right edges cut are visited by both passes, each lane by exactly one)
+            if (!er->invert)
+                ts = tileset_make(txn, tyn, rg.b0 / SHB_TB, rg.y0 / SHB_TH, (rg.b1 + SHB_TB - 1) / SHB_TB, rg.y1 / SHB_TH, false);
+            else
+                ts = tileset_make(txn, tyn, (rg.b0 + SHB_TB - 1) / SHB_TB, rg.y0 / SHB_TH, rg.b1 / SHB_TB, rg.y1 / SHB_TH, true);
+            gate = er->gate;
+        }
+        const int nt = ts.cum[ts.n];
         const bool packed = fabsf(a) * 2295.f + fabsf(c - a) * 255.f <= 32767.f && (c - a) >= 0.f; // centre weight as u16
-        if (packed)
-            hipLaunchKernelGGL(k_sharpen_box<true>, dim3(txn * tyn, 1, batch), dim3(256), 0, ctx->stream, src, dst, aux, tiles, g, a,
-                               c - a, txn, txn * tyn);
-        else
-            hipLaunchKernelGGL(k_sharpen_box<false>, dim3(txn * tyn, 1, batch), dim3(256), 0, ctx->stream, src, dst, aux, tiles, g, a,
-                               c - a, txn, txn * tyn);
+        if (nt > 0 && packed)
+            hipLaunchKernelGGL(k_sharpen_box<true>, dim3(nt, 1, batch), dim3(256), 0, ctx->stream, src, dst, aux, tiles, g, a,
+                               c - a, ts, gate, rg);
+        else if (nt > 0)
+            hipLaunchKernelGGL(k_sharpen_box<false>, dim3(nt, 1, batch), dim3(256), 0, ctx->stream, src, dst, aux, tiles, g, a,
+                               c - a, ts, gate, rg);
     } else {
         int txn = (g.w + SH_TW - 1) / SH_TW, tyn = (g.h + SH_TH - 1) / SH_TH;
         hipLaunchKernelGGL(k_sharpen, dim3(txn * tyn, 1, batch), dim3(256), 0, ctx->stream, src, dst, aux, tiles, g, k[0],

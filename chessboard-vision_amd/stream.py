@@ -45,9 +45,12 @@ class BoardPipeline:
     def configure(self, points, profile=None, grid_lines=None, rot180=False, chunk=0, lanes=0, keep_enhanced=False,
                   clahe_clip_limit=3.0, tile_grid_size=(8, 8), sharpen_kernel=None, display_size=(1280, 720), margin=100,
                   history_size=5, min_presence=0.6, change_threshold=25, z_threshold=2.5, initial_variance=100,
-                  use_hough=True, min_radius_ratio=0.20, max_radius_ratio=0.55, hough_param1=100, hough_param2=25):
+                  use_hough=True, min_radius_ratio=0.20, max_radius_ratio=0.55, hough_param1=100, hough_param2=25,
+                  enhance_region=False):
         """`use_hough` and the radii mirror PieceDetector's attributes (piece_detector.py:33-35,222-230);
-        pass min_radius / 100 and max_radius / 100 of piece_detector_settings.json as the application does."""
+        pass min_radius / 100 and max_radius / 100 of piece_detector_settings.json as the application does.
+        `enhance_region` (only without keep_enhanced): enhance the part of each frame the warp samples first and the rest
+        only when normalize's global min / max could depend on it; every output stays identical (include/cbv.h)."""
         cfg = N.PipelineConfig()
         e = cfg.enhance
         e.profile = N.ColorProfile.from_dict(profile)
@@ -77,6 +80,7 @@ class BoardPipeline:
         cfg.history_size, cfg.min_presence, cfg.change_threshold = history_size, min_presence, change_threshold
         cfg.chunk, cfg.lanes, cfg.keep_enhanced = chunk, lanes, 1 if keep_enhanced else 0
         cfg.z_threshold, cfg.initial_variance = z_threshold, initial_variance
+        cfg.enhance_region = 1 if enhance_region else 0
         cfg.use_hough = int(use_hough)  # 2 = evaluate HoughCircles on every non-uniform square (inspection)
         cfg.hough = N.HoughParams(1.2, float(hough_param1), float(hough_param2), float(min_radius_ratio), float(max_radius_ratio))
         self.ctx.check(self.ctx.lib.cbv_pipeline_configure(self.h_, cfg))

@@ -275,6 +275,11 @@ typedef struct {
                                     an OR of three detectors, so the transform runs only on the squares the other
                                     two left undecided; 2: run it on every non-uniform square (inspection) */
     cbv_hough_params hough;
+    int32_t enhance_region;      /* 1 (only with keep_enhanced = 0): CLAHE apply, bilateral and sharpen first run on the part
+                                    of each frame the warp samples (+ stencil halos); the rest of the frame is processed
+                                    only for frames whose region does not already hold both a 0 and a 255 after sharpen
+                                    (normalize's global min / max are then 0 / 255 whatever the rest holds).  Every
+                                    output is identical to whole-frame enhancement; 0 = always the whole frame */
 } cbv_pipeline_config;
 
 /* Per frame result of PieceDetector.detect_all_pieces(use_smoothing=True,
