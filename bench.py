@@ -179,6 +179,7 @@ def main():
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--no-4k", action="store_true", help="skip the configs[3] (3840x2160) leg")
     ap.add_argument("--region", action="store_true", help="time the path with cbv_pipeline_config.enhance_region = 1 (not the headline)")
+    ap.add_argument("--no-region-leg", action="store_true", help="skip the extra enhance_region = 1 leg (counter passes want whole-frame launches only)")
     ap.add_argument("--splits", type=int, default=2, help="a step's frames are enqueued as this many consecutive runs "
                     "(the temporal scan of one run overlaps the enhancement of the next)")
     args = ap.parse_args()
@@ -327,7 +328,7 @@ def main():
             ts.append((time.perf_counter() - a) * 1e3)
         single_ms = round(min(ts), 4)
     region = None
-    if rank == 0 and world == 1 and not args.no_profile_pass and not args.region:
+    if rank == 0 and world == 1 and not args.no_profile_pass and not args.region and not args.no_region_leg:
         # NOT the headline: the same stream with cbv_pipeline_config.enhance_region = 1 (CLAHE apply, bilateral and sharpen on
         # the part of each frame the warp samples; the rest only for frames whose region does not saturate to 0 and 255)
         pipe.configure(pts, profile=profile, grid_lines=grid, chunk=args.chunk, lanes=args.lanes, enhance_region=True, **S.SHIPPED_DETECTOR)

@@ -1,4 +1,4 @@
-"""Summarise rocprofv3 --pmc counter CSVs (tools/pmc_sq.sh): one table per CSV, the largest dispatch of every k_*
+"""Summarise rocprofv3 --pmc counter CSVs (tools/pmc_sq.sh): one table per CSV, the longest dispatch of every k_*
 kernel (the chunked launch), plus derived ratios when the counters are there.
 
     python tools/pmc_summary.py gpurun_out/pmc_sq/p1.csv gpurun_out/pmc_sq/p2.csv
@@ -20,8 +20,9 @@ def load(path):
         d["_grid"] = int(r["Grid_Size"])
     best = {}
     for (k, _), d in rows.items():
-        # the batched launch: largest grid, and among equal grids (persistent kernels) the longest one
-        if k not in best or d["_grid"] > best[k]["_grid"] or (d["_grid"] == best[k]["_grid"] and d["_dur"] > best[k]["_dur"]):
+        # the batched launch = the longest dispatch of the kernel (grids do not tell: a single-frame bilateral launch uses
+        # 512 workgroups of 512 lanes, the 64-frame one 256 persistent workgroups of 768)
+        if k not in best or d["_dur"] > best[k]["_dur"]:
             best[k] = d
     return best
 

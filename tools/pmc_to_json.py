@@ -28,7 +28,8 @@ whole = {"k_synth", "k_scan", "k_noise", "k_pack_results"}
 for k in sorted(F):
     if not k.startswith("k_") or k not in Wr:
         continue
-    # keep the big dispatches only (single-frame launches of calibration / profile passes are far smaller)
+    # keep the whole-frame batched dispatches only (single-frame launches are far smaller; run bench.py with
+    # --no-region-leg: the region-limited launches touch ~56 % of a frame)
     fmax = max(v for v, _ in F[k])
     fsel = [v for v, _ in F[k] if v >= 0.5 * fmax] or [fmax]
     wmax = max(v for v, _ in Wr[k])
