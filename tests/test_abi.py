@@ -43,6 +43,37 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(N.EnhanceParams) == 72 + 8 + 8 + 8 + 16 + 36 + 4
 
 
+def test_header_is_plain_c_and_every_struct_has_the_ctypes_layout(tmp_path):
+    """include/cbv.h and include/cbv_chess.h compile as C99 (what a cgo / JNI / ctypes binding needs), and the size of
+    every struct and the offset of every field the ctypes mirror names are what gcc lays out."""
+    import shutil
+    import subprocess
+    from chessboard_vision_amd import _native as N
+    if not shutil.which("gcc"):
+        pytest.skip("gcc not available")
+    pairs = [("cbv_color_profile", N.ColorProfile), ("cbv_enhance_params", N.EnhanceParams), ("cbv_roi", N.Roi),
+             ("cbv_square_view", N.SquareView), ("cbv_sq_stats", N.SqStats), ("cbv_scene", N.Scene),
+             ("cbv_hough_params", N.HoughParams), ("cbv_hough_result", N.HoughResult), ("cbv_pipeline_config", N.PipelineConfig),
+             ("cbv_frame_result", N.FrameResult), ("cbv_noise_result", N.NoiseResult), ("cbv_noise_state", N.NoiseDevState)]
+    lines = ['#include <stddef.h>', '#include <stdio.h>', '#include "cbv.h"', '#include "cbv_chess.h"', 'int main(void) {']
+    for cname, cls in pairs:
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines += ["return 0;", "}"]
+    src = tmp_path / "abi.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "abi"
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = dict(l.split() for l in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    for cname, cls in pairs:
+        assert int(got[cname]) == C.sizeof(cls), (cname, got[cname], C.sizeof(cls))
+        for fname, _ in cls._fields_:
+            assert int(got["%s.%s" % (cname, fname)]) == getattr(cls, fname).offset, (cname, fname)
+
+
 def test_no_device_means_import_error_not_fallback():
     from chessboard_vision_amd import _native as N
     lib = N.load()
