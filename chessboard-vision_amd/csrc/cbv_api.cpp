@@ -1192,7 +1192,7 @@ extern "C" int cbv_pipeline_configure(cbv_pipeline* p, const cbv_pipeline_config
                 }
             }
         }
-        if (ok && hi[0] - lo[0] < 1e6 && hi[1] - lo[1] < 1e6) {
+        if (ok && lo[0] > -1e8 && lo[1] > -1e8 && hi[0] < 1e8 && hi[1] < 1e8) { // (the casts below stay inside int)
             PxRect r = {(int)floor(lo[0]) - 3, (int)floor(lo[1]) - 3, (int)ceil(hi[0]) + 4, (int)ceil(hi[1]) + 4};
             r.x0 = std::max(r.x0, 0);
             r.y0 = std::max(r.y0, 0);
