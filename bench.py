@@ -122,6 +122,77 @@ def cpu_chain(w, h, n_frames, threads, profile, pts, grid_lines, gen_threads=Non
     return {"fps": n_frames / dt, "seconds": dt, "threads": used, "detect_loop_share": t_py / dt, "occ": occ}
 
 
+def opencv_leg(w, h, n_frames, profile, pts):
+    """when `import cv2` succeeds on the box, the same enhancement + warp through OpenCV itself (the calls
+    the reference makes, frame_enhancer.py:56-181 and board_detection.py:61-71, in a harness of our own), timed, with
+    the largest absolute pixel difference against the oracle per stage.  Without cv2 (this image has none, and nothing
+    can be installed) the leg says so.  Never raises: an OpenCV build that behaves unexpectedly is reported as text."""
+    try:
+        import cv2
+    except Exception:
+        return {"available": False, "note": "cv2 unavailable - OpenCV timing skipped (parity of the OpenCV-side arithmetic stays unpinned)"}
+    try:
+        import numpy as np
+        from oracle import cbv_oracle as O
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from helpers import oracle_frame
+        clahe = cv2.createCLAHE(clipLimit=3.0, tileGridSize=(8, 8))
+        kern = np.array([[-1, -1, -1], [-1, 9, -1], [-1, -1, -1]])
+
+        def color_profile(frame):
+            if not profile:
+                return frame
+            img = cv2.convertScaleAbs(frame, alpha=profile.get("contrast", 1.0), beta=profile.get("brightness", 0))
+            hsv = cv2.cvtColor(img, cv2.COLOR_BGR2HSV).astype(np.float32)
+            hh, ss, vv = cv2.split(hsv)
+            if profile.get("radical_mode", 0):
+                diff = np.abs(hh - profile.get("target_hue", 0))
+                diff = np.minimum(diff, 180 - diff)
+                mask = diff < profile.get("hue_window", 20)
+                ss[mask] = ss[mask] * 2.0
+                ss[~mask] = ss[~mask] * 0.5
+            hh = (hh + profile.get("hue_shift", 0)) % 180
+            ss = ss * profile.get("sat_scale", 1.0)
+            vv = vv * profile.get("val_scale", 1.0)
+            hsv = cv2.merge([np.clip(hh, 0, 179), np.clip(ss, 0, 255), np.clip(vv, 0, 255)]).astype(np.uint8)
+            return cv2.cvtColor(hsv, cv2.COLOR_HSV2BGR)
+
+        def lighting(frame):
+            lab = cv2.cvtColor(frame, cv2.COLOR_BGR2LAB)
+            l, a, b = cv2.split(lab)
+            return cv2.cvtColor(cv2.merge((clahe.apply(l), a, b)), cv2.COLOR_LAB2BGR)
+
+        stages = [("apply_color_profile", color_profile, lambda f: O.apply_color_profile(f, profile)),
+                  ("correct_lighting", lighting, O.correct_lighting),
+                  ("reduce_noise", lambda f: cv2.bilateralFilter(f, 9, 75, 75), O.bilateral),
+                  ("sharpen", lambda f: cv2.filter2D(f, -1, kern), O.filter3x3),
+                  ("normalize_intensity", lambda f: cv2.normalize(f, None, 0, 255, cv2.NORM_MINMAX), O.normalize_minmax)]
+        S_ = 620
+        M = cv2.getPerspectiveTransform(np.float32(pts), np.float32([[0, 0], [S_, 0], [0, S_], [S_, S_]]))
+        frames = [oracle_frame(w, h, "dim", frame_idx=i) for i in range(n_frames)]
+        diffs = {}
+        f_cv = f_or = frames[0]
+        for name, cv_fn, or_fn in stages:  # stage by stage on the SAME input (the oracle's), so differences do not compound
+            a, b = cv_fn(f_or), or_fn(f_or)
+            diffs[name] = int(np.abs(a.astype(np.int16) - b.astype(np.int16)).max())
+            f_or = b
+        wa = cv2.warpPerspective(f_or, M, (S_, S_))
+        wb, _, _ = O.warp_image(f_or, pts)
+        diffs["warp_image"] = int(np.abs(wa.astype(np.int16) - wb.astype(np.int16)).max())
+        t0 = time.perf_counter()
+        for f in frames:
+            for _, cv_fn, _ in stages:
+                f = cv_fn(f)
+            f_cv = cv2.warpPerspective(f, M, (S_, S_))
+        dt = time.perf_counter() - t0
+        chain = int(np.abs(f_cv.astype(np.int16) - O.warp_image(O.process_pipeline(frames[-1], profile), pts)[0].astype(np.int16)).max())
+        return {"available": True, "version": cv2.__version__, "threads": cv2.getNumThreads(), "frames": n_frames,
+                "value": round(n_frames / dt, 3), "unit": "frames/s (enhance + warp only, no detectors)",
+                "max_abs_diff_vs_oracle": diffs, "max_abs_diff_chain_warped": chain}
+    except Exception as e:  # noqa: BLE001
+        return {"available": True, "error": "%s: %s" % (type(e).__name__, e)}
+
+
 def pick_cpu_threads(profile):
     """The box may show far more CPUs in its affinity mask than its CPU share lets run at once (an OpenMP team of that
     size then thrashes): time one 640x480 frame at a few team sizes and keep the fastest."""
@@ -387,6 +458,7 @@ def main():
                 "sample": ("%d " % max(1, args.cpu_frames_1t)) + what % (w, h, 100 * c1t["detect_loop_share"]) + ", %.1f s" % c1t["seconds"]}
         c1 = c1_cpu_ms(profile, nthr)
         cpu["affinity_cpus"] = ncores
+        cpu["opencv"] = opencv_leg(w, h, min(8, args.cpu_frames), profile, pts)
         cpu["team_size_probe_ms_640x480"] = tried
         if ca["occ"] != set(S.position_for_frame(args.cpu_frames - 1).keys()):
             print("CPU oracle occupancy differs from the scripted position", file=sys.stderr)
