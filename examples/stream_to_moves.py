@@ -21,6 +21,7 @@ PLIES = len(S.SCRIPT)
 
 pipe = BoardPipeline(W, H, BATCH)
 pipe.configure(S.scaled_corners(W, H), profile=S.SHIPPED_PROFILE, grid_lines=(S.CALIB_GRID_X, S.CALIB_GRID_Y),
+               enhance_region=True,  # a fixed camera over one board: enhance what the warp samples (identical results)
                **S.SHIPPED_DETECTOR)
 game = GameState()
 stable, last = 0, None
