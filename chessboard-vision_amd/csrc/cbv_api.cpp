@@ -99,6 +99,7 @@ static void prof_drain(cbv_ctx* ctx)
 extern "C" int cbv_profile_enable(cbv_ctx* ctx, int kid)
 {
     if (!ctx) return CBV_ERR_ARG;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     prof_drain(ctx);
     ctx->prof_kid = kid;
     return CBV_OK;
@@ -107,6 +108,7 @@ extern "C" int cbv_profile_enable(cbv_ctx* ctx, int kid)
 extern "C" int cbv_profile_read(cbv_ctx* ctx, int kid, double* total_ms, long long* launches)
 {
     if (!ctx || kid < 0 || kid >= CBV_K_COUNT) return CBV_ERR_ARG;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     prof_drain(ctx);
     if (total_ms) *total_ms = ctx->prof_ms[kid];
     if (launches) *launches = ctx->prof_n[kid];
@@ -116,6 +118,7 @@ extern "C" int cbv_profile_read(cbv_ctx* ctx, int kid, double* total_ms, long lo
 extern "C" int cbv_profile_reset(cbv_ctx* ctx)
 {
     if (!ctx) return CBV_ERR_ARG;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     prof_drain(ctx);
     for (int i = 0; i < CBV_K_COUNT; i++) {
         ctx->prof_ms[i] = 0;
@@ -195,9 +198,12 @@ extern "C" int cbv_ctx_create(int device_id, cbv_ctx** out)
 extern "C" void cbv_ctx_destroy(cbv_ctx* ctx)
 {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
-    prof_drain(ctx);
+    {
+        std::lock_guard<std::recursive_mutex> lock(ctx->mu); // a call still running on another thread finishes first
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        prof_drain(ctx);
+    }
     for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
     dev_free(&ctx->in);
     dev_free(&ctx->a);
@@ -214,6 +220,7 @@ extern "C" void cbv_ctx_destroy(cbv_ctx* ctx)
 extern "C" int cbv_ctx_set_stream(cbv_ctx* ctx, void* hip_stream)
 {
     if (!ctx) return CBV_ERR_ARG;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu); // cbv_pipeline_run repoints ctx->stream while it enqueues
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     return CBV_OK;
 }
@@ -221,7 +228,12 @@ extern "C" int cbv_ctx_set_stream(cbv_ctx* ctx, void* hip_stream)
 extern "C" int cbv_ctx_synchronize(cbv_ctx* ctx)
 {
     if (!ctx) return CBV_ERR_ARG;
-    CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    hipStream_t st;
+    {
+        CBV_ENTER(ctx);
+        st = ctx->stream; // the caller's stream, never a lane a concurrent cbv_pipeline_run points at for the moment
+    }
+    CBV_HIP(ctx, hipStreamSynchronize(st));
     return CBV_OK;
 }
 
@@ -653,8 +665,11 @@ extern "C" int cbv_squares_create(cbv_ctx* ctx, cbv_squares** out)
 extern "C" void cbv_squares_destroy(cbv_squares* s)
 {
     if (!s) return;
-    (void)hipSetDevice(s->ctx->device);
-    (void)hipStreamSynchronize(s->ctx->stream);
+    {
+        std::lock_guard<std::recursive_mutex> lock(s->ctx->mu);
+        (void)hipSetDevice(s->ctx->device);
+        (void)hipStreamSynchronize(s->ctx->stream);
+    }
     DevBuf* bufs[] = {&s->d_descs, &s->d_masks, &s->d_gray, &s->d_ref, &s->d_mean, &s->d_var, &s->d_stats, &s->d_select, &s->d_coef, &s->d_stage, &s->d_hough, &s->d_retry};
     for (auto b : bufs) dev_free(b);
     delete s;
@@ -1093,6 +1108,7 @@ extern "C" int cbv_pipeline_create(cbv_ctx* ctx, int w, int h, int max_frames, c
 extern "C" void cbv_pipeline_destroy(cbv_pipeline* p)
 {
     if (!p) return;
+    std::lock_guard<std::recursive_mutex> lock(p->ctx->mu);
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
     for (int l = 0; l < cbv_pipeline::MAX_LANES; l++) {
@@ -1333,6 +1349,7 @@ extern "C" uint8_t* cbv_pipeline_host_ring(cbv_pipeline* p)
 {
     if (!p) return nullptr;
     cbv_ctx* ctx = p->ctx;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     if (!p->host_ring) {
         if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
         if (hipHostMalloc((void**)&p->host_ring, p->g.frame_stride * p->max_frames, hipHostMallocDefault) != hipSuccess) {
@@ -1498,7 +1515,13 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
                                   p->hough_cfg, hres, dec, work, b, (u32*)rec->retry.p, s0 - slot0);
     }
     ctx->stream = main_stream;
-    if (rc_all) return rc_all;
+    if (rc_all) {
+        // a launch failed after lanes were forked: whatever they already enqueued on these slots and scratch buffers must
+        // not outlive the call unordered (no RunRec goes live for a failed run)
+        for (int l = 1; l < lanes_used; l++) (void)hipStreamSynchronize(p->lane_stream[l]);
+        (void)hipStreamSynchronize(main_stream);
+        return rc_all;
+    }
     if (!p->scan_stream) {
         CBV_HIP(ctx, hipStreamCreateWithFlags(&p->scan_stream, hipStreamNonBlocking));
         CBV_HIP(ctx, hipEventCreateWithFlags(&p->main_done, hipEventDisableTiming));
@@ -1507,10 +1530,11 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
     if (!inline_scan) {
         CBV_HIP(ctx, hipEventRecord(p->main_done, main_stream));
         CBV_HIP(ctx, hipStreamWaitEvent(scan_on, p->main_done, 0));
-        for (int l = 1; l < lanes_used; l++) {
-            CBV_HIP(ctx, hipEventRecord(p->lane_done[l], p->lane_stream[l]));
-            CBV_HIP(ctx, hipStreamWaitEvent(scan_on, p->lane_done[l], 0));
-        }
+    }
+    // every forked lane is joined, in the inline case too (chunk = 1 puts the second frame of a two-frame run on lane 1)
+    for (int l = 1; l < lanes_used; l++) {
+        CBV_HIP(ctx, hipEventRecord(p->lane_done[l], p->lane_stream[l]));
+        CBV_HIP(ctx, hipStreamWaitEvent(scan_on, p->lane_done[l], 0));
     }
     // every lane has read its frames: a later cbv_pipeline_submit may overwrite these slots after this event
     CBV_HIP(ctx, hipEventRecord(rec->lanes_ev, scan_on));
@@ -1592,9 +1616,14 @@ extern "C" int cbv_pipeline_results(cbv_pipeline* p, int slot0, int count, cbv_f
     CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     memcpy(out, p->h_stage, bytes);
     const u32 over = *over_h;
-    if (over) // a truncated candidate list may change has_piece: never hand that over as if it were HoughCircles' answer
-        return cbv_fail(ctx, CBV_ERR_UNSUPPORTED, "HoughCircles: the candidate list overflowed (more than 512 accumulator maxima) on %u square(s) "
-                        "since the last reset_state; those occupancy bits are not HoughCircles' (inspect cbv_pipeline_hough flags)", over);
+    if (over) {
+        // A truncated candidate list may change has_piece: never hand that over as if it were HoughCircles' answer.  The
+        // counter is cleared on read, so the error is reported ONCE, by the first results call after the runs it
+        // happened in, and later frames are not poisoned; `out` is filled and valid except for the flagged squares.
+        CBV_HIP(ctx, hipMemsetAsync(p->d_hough_over.p, 0, 4, ctx->stream));
+        return cbv_fail(ctx, CBV_ERR_UNSUPPORTED, "HoughCircles: the candidate list overflowed even the second pass on %u square(s) since the "
+                        "previous cbv_pipeline_results; those occupancy bits are not HoughCircles' (cbv_pipeline_hough flags name the squares)", over);
+    }
     return CBV_OK;
 }
 

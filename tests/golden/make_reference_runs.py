@@ -21,7 +21,7 @@ their outputs are written as data files under tests/golden/:
   ref_change_planes.npz        a few mean / variance planes of that run (all planes are covered by sha256)
   ref_refine_grid.json         SmartGridExtractor.refine_grid                                (grid_extractor.py:66-121)
   ref_cython_twins.json        ImageEnhancerCython / ChangeDetectorCython (src/cython/*.pyx, built by
-                               oracle/build_ref_cython.sh into oracle/_ref/) on the same inputs: identical or not
+                               oracle/build_ref_cython.sh into a scratch directory) on the same inputs: identical or not
 
 What these pin: see cv2_oracle_shim.py — the reference's numpy arithmetic and control flow exactly; the OpenCV-side
 pixel numbers are the oracle's own (circular) and stay "parity unpinned".
@@ -472,12 +472,17 @@ def gold_change_sequence():
 
 def gold_cython_twins():
     """The reference's Cython twins (src/cython/*.pyx: the slot its selector fills first, frame_enhancer.py:12-21),
-    compiled by oracle/build_ref_cython.sh into oracle/_ref/, driven on the same inputs as the Python classes above.
+    compiled by oracle/build_ref_cython.sh into a scratch directory, driven on the same inputs as the Python classes above.
     Records whether every output is identical; the HIP classes are compared with the Python classes' fixtures, so
     this is what makes those fixtures speak for the Cython twins too."""
-    ref_dir = os.path.join(ROOT, "oracle", "_ref")
+    # built into the generator's scratch directory (outside the repository, removed with it): compiled reference code
+    # never sits in the tree that travels to the GPU box
+    import subprocess
+    ref_dir = os.path.join(_SCRATCH, "cython_twins")
     out = {"built": False}
-    if not os.path.isdir(os.path.join(ref_dir, "src", "cython")):
+    try:
+        subprocess.check_call(["bash", os.path.join(ROOT, "oracle", "build_ref_cython.sh"), REF, ref_dir], stdout=subprocess.DEVNULL)
+    except (subprocess.CalledProcessError, OSError):
         with open(os.path.join(OUT, "ref_cython_twins.json"), "w") as f:
             json.dump(out, f)
         return

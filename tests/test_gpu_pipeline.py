@@ -131,6 +131,46 @@ def test_frame_at_a_time_equals_one_batched_run(gpu_ctx):
     p.close()
 
 
+def test_two_frame_run_with_one_frame_chunks_joins_its_second_lane(gpu_ctx):
+    """chunk = 1 with two lanes puts frame s + 1 of run(s, 2) on the second lane while the scan stays on the caller's
+    stream (runs of <= 2 frames): the scan, a following submit / configure and results() must all be ordered after
+    that lane.  Compared with chunk = 2 on one lane, repeatedly (an unjoined lane shows as a differing or changing
+    result), then run(0, 2) followed at once by a reconfigure that frees the lanes' scratch."""
+    from chessboard_vision_amd.stream import BoardPipeline
+    n = 12
+    pts = S.scaled_corners(W, H)
+
+    def drive(chunk, lanes):
+        p = BoardPipeline(W, H, n)
+        p.configure(pts, profile=S.SHIPPED_PROFILE, chunk=chunk, lanes=lanes, **S.SHIPPED_DETECTOR)
+        p.synth(0, n, scene="dim", frames_per_ply=2)
+        outs = []
+        for rep in range(3):
+            p.reset_state()
+            for s0 in range(0, n, 2):
+                p.run(s0, 2)
+            res = [(r.raw_occupied, r.stable_occupied, r.visual_changes, r.processed) for r in p.results(0, n)]
+            hough = [[(h.flags, h.found, h.cx, h.cy, h.r) for h in p.hough(i)] for i in range(n)]
+            outs.append((res, hough, [p.download(2, i) for i in range(n)]))
+        return p, outs
+
+    p1, want = drive(2, 1)
+    p2, got = drive(1, 2)
+    for o in want[1:] + got:
+        assert o[0] == want[0][0] and o[1] == want[0][1]
+        for a, b in zip(o[2], want[0][2]):
+            assert np.array_equal(a, b)
+    # run + immediate reconfigure (frees A / B of both lanes) + run again: no fault, same answer
+    p2.reset_state()
+    p2.run(0, 2)
+    p2.configure(pts, profile=S.SHIPPED_PROFILE, chunk=1, lanes=2, **S.SHIPPED_DETECTOR)
+    p2.run(0, 2)
+    res = [(r.raw_occupied, r.stable_occupied, r.visual_changes, r.processed) for r in p2.results(0, 2)]
+    assert res == want[0][0][:2]
+    p1.close()
+    p2.close()
+
+
 def test_upload_path_equals_synth_path(gpu_ctx):
     from chessboard_vision_amd.stream import BoardPipeline
     pts = S.scaled_corners(W, H)
