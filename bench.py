@@ -235,6 +235,69 @@ def c1_cpu_ms(profile, threads):
     return out
 
 
+def class_api_leg(frames, w, h, pts, grid, profile, detector_kw, frames_per_ply=32, frame0=0):
+    """The reference's OWN per-frame call pattern through the drop-in classes (PCIe-inclusive, host numpy frames in,
+    Python dicts out; never the bench's `value`): GameSession.on_frame (game_session.py:124-161) calls
+    warp_image -> split_board -> detect_all_pieces(squares, use_delta=True, squares_to_check=...) once per camera frame;
+    the composed chain of the north star puts ImageEnhancer.process_pipeline in front.  Median milliseconds per frame over
+    the given frames (the bench's own stream, downloaded), every frame's raw occupancy checked against the script."""
+    import statistics
+    from chessboard_vision_amd import synth as S
+    from chessboard_vision_amd.board_detection import warp_image
+    from chessboard_vision_amd.frame_enhancer import ImageEnhancer
+    from chessboard_vision_amd.grid_extractor import SmartGridExtractor
+    from chessboard_vision_amd.piece_detector import PieceDetector
+    ge = SmartGridExtractor()
+    ge.grid_lines_x, ge.grid_lines_y = list(grid[0]), list(grid[1])
+    enh = ImageEnhancer()
+    enh.profile = dict(profile)
+    middle = {(f, r) for f in range(8) for r in (2, 3, 4, 5) if (f + r) % 2 == 0}  # stand-in for the legal destinations
+
+    def check_set(i):
+        # game_session.py:130-152: a full scan every 30th frame, else the occupied squares + the legal destinations
+        return None if i % 30 == 0 else (set(S.position_for_frame(frame0 + i, frames_per_ply).keys()) | middle)
+
+    def new_detector():
+        d = PieceDetector()
+        d.min_radius_ratio, d.max_radius_ratio = detector_kw["min_radius_ratio"], detector_kw["max_radius_ratio"]
+        return d
+
+    out = {}
+    ok = True
+    for name, with_enhance in (("warp_split_detect_ms", False), ("enhance_warp_split_detect_ms", True)):
+        det = new_detector()
+        t_total, t_enh, t_warp, t_split, t_det = [], [], [], [], []
+        for rep_ in range(2):  # first pass warms every buffer / table up and is not counted
+            for i, f in enumerate(frames):
+                a = time.perf_counter()
+                img = enh.process_pipeline(f) if with_enhance else f
+                b = time.perf_counter()
+                warped, _, _ = warp_image(img, pts)
+                c = time.perf_counter()
+                squares = ge.split_board(warped)
+                d = time.perf_counter()
+                results, visual = det.detect_all_pieces(squares, use_delta=True, squares_to_check=check_set(i))
+                e = time.perf_counter()
+                if rep_ == 1:
+                    t_total.append(e - a); t_enh.append(b - a); t_warp.append(c - b); t_split.append(d - c); t_det.append(e - d)
+                    if with_enhance:
+                        raw = {p for p, r in det.cached_results.items() if r["has_piece"]}
+                        ok = ok and raw == set(S.position_for_frame(frame0 + i, frames_per_ply).keys())
+        med = lambda v: round(statistics.median(v) * 1e3, 4)
+        out[name] = med(t_total)
+        out[name.replace("_ms", "_breakdown_ms")] = {"process_pipeline": med(t_enh) if with_enhance else None, "warp_image": med(t_warp),
+                                                      "split_board": med(t_split), "detect_all_pieces": med(t_det),
+                                                      "worst_frame": round(max(t_total) * 1e3, 4)}
+    out["frames"] = len(frames)
+    out["occupancy_check"] = bool(ok)
+    out["note"] = ("the reference's own per-frame calls through the drop-in classes (game_session.py:124-161), one %dx%d numpy frame at a time, "
+                   "host memory in and Python dicts out (PCIe-inclusive; not `value`): warp_image uploads the frame rows the quad covers "
+                   "and downloads the board, detect_all_pieces uploads the board AT CALL TIME and does preprocess, reference "
+                   "comparison, gate, HoughCircles on the squares the reference would run it on and the decision in one library call; "
+                   "squares_to_check given on 29 of 30 frames like the session's smart scan" % (w, h))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -251,6 +314,7 @@ def main():
     ap.add_argument("--no-4k", action="store_true", help="skip the configs[3] (3840x2160) leg")
     ap.add_argument("--region", action="store_true", help="time the path with cbv_pipeline_config.enhance_region = 1 (not the headline)")
     ap.add_argument("--no-region-leg", action="store_true", help="skip the extra enhance_region = 1 leg (counter passes want whole-frame launches only)")
+    ap.add_argument("--no-class-api", action="store_true", help="skip the class-API (one host frame per call) leg")
     ap.add_argument("--splits", type=int, default=2, help="a step's frames are enqueued as this many consecutive runs "
                     "(the temporal scan of one run overlaps the enhancement of the next)")
     args = ap.parse_args()
@@ -421,6 +485,13 @@ def main():
                           "kernels touch about 57 % of each 1080p frame for the calibration quad, so this figure is NOT priced against "
                           "SURVEY 8(d)'s whole-frame bytes and is not the bench's value"}
         occ_ok = occ_ok and okr
+    class_api = None
+    if rank == 0 and world == 1 and not args.no_profile_pass and not args.no_class_api:
+        nf = min(F, 48)
+        host_frames = [pipe.download(0, i) for i in range(nf)]  # the bench's own stream as camera frames in host memory
+        class_api = class_api_leg(host_frames, w, h, pts, grid, profile, S.SHIPPED_DETECTOR)
+        occ_ok = occ_ok and class_api["occupancy_check"]
+        del host_frames
     if rank == 0 and world == 1 and not args.no_4k and not args.no_profile_pass:
         # configs[3]: 3840x2160 frames, bilateral d = 9, device-resident (warp / detect unchanged at 620x620)
         pipe.close()
@@ -526,7 +597,7 @@ def main():
                               "note": "SURVEY 8(d) algorithmic bytes (enhance = 10 N) although the timed path never materialises process_pipeline's "
                                       "output: normalize is folded into the warp gather (keep_enhanced = 0); a caller that wants the enhanced frame "
                                       "pays one more 2N pass (k_normalize)"},
-            "kernels": kernels, "single_frame_ms": single_ms, "region_limited": region, "c4_fps": c4, "cpu_baseline": cpu, "cpu_baseline_1t": cpu1, "c1_cpu_ms": c1,
+            "kernels": kernels, "single_frame_ms": single_ms, "class_api": class_api, "region_limited": region, "c4_fps": c4, "cpu_baseline": cpu, "cpu_baseline_1t": cpu1, "c1_cpu_ms": c1,
             "occupancy_check": bool(occ_ok), "hough_squares_last_frame": hough_ran,
             "device": ctx.name,
         }

@@ -93,6 +93,42 @@ class HoughResult(C.Structure):
                 ("flags", C.c_uint16), ("circles", (C.c_float * 4) * HOUGH_KEEP)]
 
 
+class HostImage(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("w", C.c_int32), ("h", C.c_int32), ("stride", C.c_int32), ("cn", C.c_int32)]
+
+
+METHOD_NAMES = (None, "hough", "tower_top", "center_diff", "symmetry")
+
+
+class PieceResult(C.Structure):
+    _fields_ = [("has_piece", C.c_uint8), ("method", C.c_uint8), ("changed", C.c_uint8), ("should_process", C.c_uint8),
+                ("evaluated", C.c_uint8), ("pad", C.c_uint8 * 3), ("cx", C.c_int32), ("cy", C.c_int32), ("radius", C.c_int32),
+                ("confidence", C.c_double), ("center_border_diff", C.c_double)]
+
+
+class DetectParams(C.Structure):
+    _fields_ = [("change_threshold", C.c_double), ("circle_threshold", C.c_double), ("hough", HoughParams),
+                ("has_ref", C.c_uint64), ("cached", C.c_uint64), ("check", C.c_uint64), ("check_given", C.c_int32),
+                ("use_delta", C.c_int32)]
+
+
+class ChangeParams(C.Structure):
+    _fields_ = [("z_threshold", C.c_double), ("select", C.c_uint64), ("circle_threshold", C.c_double), ("hough", HoughParams)]
+
+
+class ChangeResult(C.Structure):
+    _fields_ = [("in_result", C.c_uint8), ("intensity", C.c_uint8), ("is_circular", C.c_uint8), ("pad", C.c_uint8),
+                ("z_max", C.c_float), ("z_count", C.c_uint32), ("n", C.c_uint32)]
+
+
+def record_dtype(struct, skip=("pad",)):
+    """numpy dtype with the layout of a ctypes Structure (padding fields left out): an array of it is filled by the
+    library in place and `.tolist()` turns all records into Python scalars in one call."""
+    names = [n for n, _ in struct._fields_ if n not in skip]
+    return np.dtype({"names": names, "formats": [np.dtype(dict(struct._fields_)[n]) for n in names],
+                     "offsets": [getattr(struct, n).offset for n in names], "itemsize": C.sizeof(struct)})
+
+
 class PipelineConfig(C.Structure):
     _fields_ = [("enhance", EnhanceParams), ("M", C.c_double * 9), ("board_size", C.c_int32), ("rot180", C.c_int32),
                 ("n_rois", C.c_int32), ("rois", Roi * MAX_SQUARES), ("history_size", C.c_int32),
@@ -173,6 +209,12 @@ def load():
         "cbv_find_chessboard_corners": (i32, [vp, u8p, i32, i32, i32, C.POINTER(C.c_int32), u8p, i32]),
         "cbv_canny": (i32, [vp, u8p, i32, i32, i32, i32, dbl, dbl, u8p, i32]),
         "cbv_squares_hough": (i32, [vp, P(HoughParams), P(HoughResult)]),
+        "cbv_squares_load_image": (i32, [vp, P(HostImage), P(Roi), i32, i32]),
+        "cbv_squares_set_ref_mask": (i32, [vp, C.c_uint64]),
+        "cbv_decide_piece": (i32, [P(SqStats), P(HoughResult), i32, i32, dbl, P(PieceResult)]),
+        "cbv_squares_detect_all": (i32, [vp, P(HostImage), P(Roi), i32, P(DetectParams), vp]),
+        "cbv_squares_detect_changes": (i32, [vp, P(HostImage), P(Roi), i32, i32, P(ChangeParams), vp]),
+        "cbv_debug_poison": (i32, [vp, i32]),
         "cbv_squares_get": (i32, [vp, i32, i32, vp]),
         "cbv_squares_set": (i32, [vp, i32, i32, vp]),
         "cbv_squares_geometry": (i32, [vp, i32, P(i32), P(i32)]),

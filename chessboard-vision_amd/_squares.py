@@ -17,6 +17,67 @@ def _as_view_array(img):
     return a if ok else np.ascontiguousarray(a)
 
 
+def _image_of(parent):
+    """cbv_host_image of a uint8 HxW / HxWx3 array with contiguous pixels (any row stride), or None."""
+    if not isinstance(parent, np.ndarray) or parent.dtype != np.uint8 or parent.ndim not in (2, 3):
+        return None
+    cn = 1 if parent.ndim == 2 else parent.shape[2]
+    if cn not in (1, 3) or parent.shape[0] <= 0 or parent.shape[1] <= 0:
+        return None
+    st = parent.strides
+    if st[-1] != 1 or (parent.ndim == 3 and st[1] != 3) or st[0] < parent.shape[1] * cn:
+        return None
+    img = N.HostImage()
+    img.data = parent.ctypes.data
+    img.w, img.h, img.stride, img.cn = parent.shape[1], parent.shape[0], st[0], cn
+    img._keep = parent
+    return img
+
+
+def plan_of(squares):
+    """(cbv_host_image, SquareLayout) when every value of `squares` is a view into one uint8 image (split_board's case,
+    grid_extractor.py:46,153), else None.  A SquareDict from this package's split_board carries the answer.  Any other
+    mapping is analysed through the views themselves: they must share their owner (`.base`; numpy collapses chains of
+    views to the array that owns the memory), their strides, and lie on whole pixels of the rows those strides define
+    over the owner's block, which is then the image (e.g. a frame that is itself a reshape of a capture buffer)."""
+    from .grid_extractor import SquareDict, SquareLayout
+    if type(squares) is SquareDict and squares._parent is not None and len(squares) == len(squares._layout.keys):
+        img = _image_of(squares._parent)
+        if img is not None:
+            return img, squares._layout
+    if not squares or len(squares) > N.MAX_SQUARES:
+        return None
+    vals = list(squares.values())
+    a0 = vals[0]
+    if not isinstance(a0, np.ndarray) or a0.dtype != np.uint8 or a0.ndim not in (2, 3) or (a0.ndim == 3 and a0.shape[2] != 3):
+        return None
+    owner = a0.base if a0.base is not None else a0
+    if not isinstance(owner, np.ndarray) or not (owner.flags.c_contiguous or owner.flags.f_contiguous):
+        return None
+    cn = 1 if a0.ndim == 2 else 3
+    st = a0.strides
+    if st[-1] != 1 or (a0.ndim == 3 and st[1] != 3) or st[0] < a0.shape[1] * cn:
+        return None
+    b0, row = owner.ctypes.data, st[0]
+    rows_full = owner.nbytes // row  # whole rows of `row` bytes inside the owner's block
+    rects = []
+    for a in vals:
+        if not isinstance(a, np.ndarray) or (a.base if a.base is not None else a) is not owner or a.dtype != np.uint8 or a.strides != st:
+            return None
+        if a.shape[0] <= 0 or a.shape[1] <= 0:
+            return None
+        y0, xb = divmod(a.ctypes.data - b0, row)
+        x0, rem = divmod(xb, cn)
+        if rem or xb + a.shape[1] * cn > row or y0 < 0 or y0 + a.shape[0] > rows_full:
+            return None
+        rects.append((x0, y0, a.shape[1], a.shape[0]))
+    img = N.HostImage()
+    img.data = b0
+    img.w, img.h, img.stride, img.cn = row // cn, rows_full, row, cn
+    img._keep = owner
+    return img, SquareLayout(list(squares.keys()), rects)
+
+
 class SquareSet:
     def __init__(self, ctx=None):
         self.ctx = ctx or N.context()
@@ -26,6 +87,9 @@ class SquareSet:
         self.keys = []     # position of each index
         self.index = {}
         self.shapes = []
+        self._layout = None  # SquareLayout of the last image-based load (identity check on the per-frame path)
+        self._piece_out = np.zeros(N.MAX_SQUARES, N.record_dtype(N.PieceResult))
+        self._change_out = np.zeros(N.MAX_SQUARES, N.record_dtype(N.ChangeResult))
 
     def close(self):
         if self.h:
@@ -43,6 +107,10 @@ class SquareSet:
         fixed to that list and positions missing from `squares` keep their
         current gray.  Returns True when the geometry (keys/shapes) changed,
         i.e. all device state was reset."""
+        plan = plan_of(squares) if (keys is None or len(squares) == len(keys)) else None
+        if plan is not None and (keys is None or list(keys) == plan[1].keys):
+            return self.load_image(plan[0], plan[1], blur_k)
+        self._layout = None
         order = list(squares.keys()) if keys is None else list(keys)
         arrs = [(_as_view_array(squares[k]) if k in squares else None) for k in order]
         shapes = [(a.shape[0], a.shape[1]) if a is not None else None for a in arrs]
@@ -66,6 +134,39 @@ class SquareSet:
             self.index = {k: i for i, k in enumerate(order)}
             self.shapes = [s for s in shapes]
         return changed
+
+    def adopt(self, lay):
+        """Take over the keys / shapes of a layout; True when they differ from the current ones (the device state of
+        the squares is then void, exactly as after load() of a changed geometry)."""
+        if lay is self._layout:
+            return False
+        changed = lay.keys != self.keys or lay.shapes != self.shapes
+        if changed:
+            self.keys, self.index, self.shapes = lay.keys, lay.index, lay.shapes
+        self._layout = lay
+        return changed
+
+    def load_image(self, img, lay, blur_k):
+        """load() for squares that are all views of one image: one upload of the rows they cover, at call time."""
+        changed = self.adopt(lay)
+        self.ctx.check(self.ctx.lib.cbv_squares_load_image(self.h, img, lay.rois, len(lay.keys), int(blur_k)))
+        return changed
+
+    def set_ref_mask(self, mask):
+        self.ctx.check(self.ctx.lib.cbv_squares_set_ref_mask(self.h, int(mask)))
+
+    def detect_all(self, img, lay, prm):
+        """cbv_squares_detect_all; returns one tuple per square (has_piece, method, changed, should_process, evaluated,
+        cx, cy, radius, confidence, center_border_diff) as Python scalars."""
+        n = len(lay.keys)
+        self.ctx.check(self.ctx.lib.cbv_squares_detect_all(self.h, img, lay.rois, n, prm, self._piece_out.ctypes.data))
+        return self._piece_out[:n].tolist()
+
+    def detect_changes(self, img, lay, blur_k, prm):
+        """cbv_squares_detect_changes; one tuple per square (in_result, intensity, is_circular, z_max, z_count, n)."""
+        n = len(lay.keys)
+        self.ctx.check(self.ctx.lib.cbv_squares_detect_changes(self.h, img, lay.rois, n, int(blur_k), prm, self._change_out.ctypes.data))
+        return self._change_out[:n].tolist()
 
     def _select(self, positions):
         if positions is None:

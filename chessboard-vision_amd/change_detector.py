@@ -6,8 +6,11 @@ on the GPU; `means` / `variances` are dict-like views that fetch a plane when
 read.  Scalar attributes (z_threshold, initial_variance, alpha, blur_kernel)
 are plain and read at call time, as calibrate_sensitivity.py:135-139 expects.
 """
-from ._squares import MEAN, VAR, PlaneDict, SquareSet
+from . import _native as N
+from ._squares import MEAN, VAR, PlaneDict, SquareSet, plan_of
 from .piece_detector import PieceDetector
+
+_INTENSITY = (None, "LEVE", "PARCIAL", "TOTAL")
 
 
 class ChangeDetectorHIP:
@@ -25,6 +28,7 @@ class ChangeDetectorHIP:
         self.focus_squares = set()
 
         self.piece_detector = PieceDetector()
+        self._prm = N.ChangeParams()
 
     def _k(self):
         return int(self.blur_kernel) | 1
@@ -75,10 +79,40 @@ class ChangeDetectorHIP:
         return {pos: info["pct_changed"] for pos, info in detailed.items() if info["intensity"] in ["PARCIAL", "TOTAL"]}
 
     def detect_changes_detailed(self, squares):
-        """change_detector.py:105-167"""
+        """change_detector.py:105-167.  For a split_board dict (all squares views of one image) the device half is one
+        library call: upload of the board at call time, _preprocess, z-scores against the device-resident model, and
+        the circular test of the squares that changed."""
         results = {}
         if not self.is_calibrated:
             return results
+        plan = plan_of(squares)
+        if plan is None or plan[1].keys != self._state.keys or plan[1].shapes != self._state.shapes:
+            return self._detect_changes_detailed_views(squares)
+        img, lay = plan
+        self._state.adopt(lay)
+        to_check = self.focus_squares if self.focus_squares else squares.keys()
+        means = self.means
+        prm = self._prm
+        prm.z_threshold = float(self.z_threshold)
+        prm.select = lay.mask(pos for pos in to_check if pos in means)
+        pd = self.piece_detector
+        prm.circle_threshold = float(pd.circle_threshold)
+        pd._fill_hough(prm.hough)
+        rows = self._state.detect_changes(img, lay, self._k(), prm)
+        index = lay.index
+        for pos in to_check:  # the reference's dict is in this order
+            i = index.get(pos)
+            if i is None:
+                continue
+            in_result, intensity, is_circular, z_max, z_count, n = rows[i]
+            if in_result:
+                results[pos] = {"z_score": z_max, "pct_changed": (z_count / n) * 100, "intensity": _INTENSITY[intensity],
+                                "is_circular": bool(is_circular), "center_ratio": 1.0}
+        return results
+
+    def _detect_changes_detailed_views(self, squares):
+        """The same for squares that are not views of one image, a subset of the calibrated squares, or new geometry."""
+        results = {}
         self._load(squares)
         st = self._state.stats(use_model=True, z_threshold=self.z_threshold)
         to_check = self.focus_squares if self.focus_squares else squares.keys()

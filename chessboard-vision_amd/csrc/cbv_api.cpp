@@ -6,6 +6,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
+#include <stdlib.h>
 
 #include "cbv_internal.h"
 
@@ -32,9 +34,27 @@ int dev_ensure(cbv_ctx* ctx, DevBuf* b, size_t bytes)
         b->p = nullptr;
         b->cap = 0;
     }
-    size_t cap = (bytes + 4095) & ~(size_t)4095;
+    // whole 2 MiB units for anything large: the driver can then map the buffer with large GPU pages
+    size_t cap = bytes >= (256u << 10) ? (bytes + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1) : (bytes + 4095) & ~(size_t)4095;
     CBV_HIP(ctx, hipMalloc(&b->p, cap));
     b->cap = cap;
+    return CBV_OK;
+}
+
+int ctx_hstage(cbv_ctx* ctx, size_t bytes, u8** p)
+{
+    if (ctx->h_stage_cap < bytes) {
+        if (ctx->h_stage) {
+            CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            (void)hipHostFree(ctx->h_stage);
+        }
+        ctx->h_stage = nullptr;
+        ctx->h_stage_cap = 0;
+        const size_t cap = (bytes + 65535) & ~(size_t)65535;
+        CBV_HIP(ctx, hipHostMalloc((void**)&ctx->h_stage, cap, hipHostMallocDefault));
+        ctx->h_stage_cap = cap;
+    }
+    *p = ctx->h_stage;
     return CBV_OK;
 }
 
@@ -213,6 +233,7 @@ extern "C" void cbv_ctx_destroy(cbv_ctx* ctx)
     if (ctx->tabs) (void)hipFree(ctx->tabs);
     if (ctx->ptabs) (void)hipFree(ctx->ptabs);
     if (ctx->btabs) (void)hipFree(ctx->btabs);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -297,17 +318,40 @@ static Geom tight_geom(int w, int h)
     return g;
 }
 
+#define RC(x)             \
+    do {                  \
+        int rc__ = (x);   \
+        if (rc__) return rc__; \
+    } while (0)
+
+// rows between a host image (any row stride) and a tight device image, asynchronous.  Tight host rows travel as ONE
+// linear copy: the 2-D entry point takes a slower path even when width == pitch (a 1080p frame to pageable memory:
+// 365 us against 119 us, tools/ubench_copy.hip).
+static int rows_h2d(cbv_ctx* ctx, void* dst, const u8* src, int stride, int wbytes, int h)
+{
+    if (stride == wbytes) CBV_HIP(ctx, hipMemcpyAsync(dst, src, (size_t)wbytes * h, hipMemcpyHostToDevice, ctx->stream));
+    else CBV_HIP(ctx, hipMemcpy2DAsync(dst, wbytes, src, stride, wbytes, h, hipMemcpyHostToDevice, ctx->stream));
+    return CBV_OK;
+}
+
+static int rows_d2h(cbv_ctx* ctx, u8* dst, int stride, const void* src, int wbytes, int h)
+{
+    if (stride == wbytes) CBV_HIP(ctx, hipMemcpyAsync(dst, src, (size_t)wbytes * h, hipMemcpyDeviceToHost, ctx->stream));
+    else CBV_HIP(ctx, hipMemcpy2DAsync(dst, stride, src, wbytes, wbytes, h, hipMemcpyDeviceToHost, ctx->stream));
+    return CBV_OK;
+}
+
 static int upload(cbv_ctx* ctx, DevBuf* dst, const u8* src, int wbytes, int h, int stride)
 {
     int rc = dev_ensure(ctx, dst, (size_t)wbytes * h + 256);
     if (rc) return rc;
-    CBV_HIP(ctx, hipMemcpy2DAsync(dst->p, wbytes, src, stride, wbytes, h, hipMemcpyHostToDevice, ctx->stream));
-    return CBV_OK;
+    return rows_h2d(ctx, dst->p, src, stride, wbytes, h);
 }
 
 static int download(cbv_ctx* ctx, const void* src, u8* dst, int wbytes, int h, int stride)
 {
-    CBV_HIP(ctx, hipMemcpy2DAsync(dst, stride, src, wbytes, wbytes, h, hipMemcpyDeviceToHost, ctx->stream));
+    int rc = rows_d2h(ctx, dst, stride, src, wbytes, h);
+    if (rc) return rc;
     CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return CBV_OK;
 }
@@ -337,11 +381,6 @@ static int small_layout(cbv_ctx* ctx, DevBuf* buf, int tiles, int batch, SmallLa
     return CBV_OK;
 }
 
-#define RC(x)             \
-    do {                  \
-        int rc__ = (x);   \
-        if (rc__) return rc__; \
-    } while (0)
 
 extern "C" int cbv_apply_color_profile(cbv_ctx* ctx, const uint8_t* bgr, int w, int h, int stride,
                                        const cbv_color_profile* profile, uint8_t* out, int out_stride)
@@ -466,8 +505,8 @@ extern "C" int cbv_prepare_analysis(cbv_ctx* ctx, const uint8_t* bgr, int w, int
     RC(launch_gray_blur_hist(ctx, (const u8*)ctx->in.p, dgray, dblur, S.aux, 1, g, 1));
     RC(launch_otsu(ctx, S.aux, 1, w * h, 1));
     RC(launch_threshold(ctx, dblur, dbin, S.aux, 1, w, h, 1));
-    CBV_HIP(ctx, hipMemcpy2DAsync(gray, gray_stride, dgray, w, w, h, hipMemcpyDeviceToHost, ctx->stream));
-    CBV_HIP(ctx, hipMemcpy2DAsync(binary, binary_stride, dbin, w, w, h, hipMemcpyDeviceToHost, ctx->stream));
+    RC(rows_d2h(ctx, gray, gray_stride, dgray, w, h));
+    RC(rows_d2h(ctx, binary, binary_stride, dbin, w, h));
     u32 t = 0;
     CBV_HIP(ctx, hipMemcpyAsync(&t, S.aux + (size_t)1 * 256 + 2 + 256, 4, hipMemcpyDeviceToHost, ctx->stream));
     CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -488,7 +527,7 @@ extern "C" int cbv_canny(cbv_ctx* ctx, const uint8_t* img, int w, int h, int str
     size_t plane = ((size_t)w * h + 255) & ~(size_t)255;
     RC(dev_ensure(ctx, &ctx->a, plane));
     RC(launch_canny(ctx, (const u8*)ctx->in.p, w, h, w * cn, cn, low, high, (u8*)ctx->a.p, &ctx->b));
-    CBV_HIP(ctx, hipMemcpy2DAsync(edges, edges_stride, ctx->a.p, w, w, h, hipMemcpyDeviceToHost, ctx->stream));
+    RC(rows_d2h(ctx, edges, edges_stride, ctx->a.p, w, h));
     CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return CBV_OK;
 }
@@ -596,6 +635,34 @@ static int enhance_dev(cbv_ctx* ctx, const u8* src, u8* A, u8* B, Geom g, const 
     return CBV_OK;
 }
 
+// Source pixels a dw x dh warp can sample: the image of the destination rectangle under Minv (a projective map keeps it
+// convex while W > 0 on it, so its four corners bound it), + 3 px for the 1/32-px rounding and the bilinear taps, clipped
+// to the frame.  False when the map is degenerate on the rectangle or the footprint is empty: callers then take the
+// whole frame.
+static bool warp_footprint(const double* Minv, int dw, int dh, int w, int h, PxRect* out)
+{
+    double lo[2] = {1e30, 1e30}, hi[2] = {-1e30, -1e30};
+    for (int k = 0; k < 4; k++) {
+        const double dx = (k & 1) ? dw - 1 : 0, dy = (k & 2) ? dh - 1 : 0;
+        const double W = Minv[6] * dx + Minv[7] * dy + Minv[8];
+        if (!(W > 1e-12)) return false;
+        const double c[2] = {(Minv[0] * dx + Minv[1] * dy + Minv[2]) / W, (Minv[3] * dx + Minv[4] * dy + Minv[5]) / W};
+        for (int a = 0; a < 2; a++) {
+            lo[a] = std::min(lo[a], c[a]);
+            hi[a] = std::max(hi[a], c[a]);
+        }
+    }
+    if (!(lo[0] > -1e8 && lo[1] > -1e8 && hi[0] < 1e8 && hi[1] < 1e8)) return false; // (the casts below stay inside int)
+    PxRect r = {(int)floor(lo[0]) - 3, (int)floor(lo[1]) - 3, (int)ceil(hi[0]) + 4, (int)ceil(hi[1]) + 4};
+    r.x0 = std::max(r.x0, 0);
+    r.y0 = std::max(r.y0, 0);
+    r.x1 = std::min(r.x1, w);
+    r.y1 = std::min(r.y1, h);
+    if (r.x1 <= r.x0 || r.y1 <= r.y0) return false;
+    *out = r;
+    return true;
+}
+
 static int check_params(cbv_ctx* ctx, const cbv_enhance_params* P)
 {
     if (!P) return cbv_fail(ctx, CBV_ERR_ARG, "enhance params are null");
@@ -631,11 +698,31 @@ extern "C" int cbv_warp_perspective(cbv_ctx* ctx, const uint8_t* bgr, int w, int
     CBV_ENTER(ctx);
     double Minv[9];
     if (!host_invert3x3(M9, Minv)) memset(Minv, 0, sizeof(Minv)); // cv::invert returns a zero matrix when singular
-    RC(upload(ctx, &ctx->in, bgr, w * 3, h, stride));
+    // Only the rows of the frame the warp can sample cross PCIe (the board quad's rows; whole rows, because a 2-D copy
+    // with a wide pitch runs at a fifth of the rate of a contiguous one on this platform: tools/ubench_copy.hip).  The
+    // rest of the device buffer is never read.
+    PxRect fp;
+    int y0 = 0, y1 = h;
+    if (warp_footprint(Minv, dw, dh, w, h, &fp)) {
+        y0 = fp.y0;
+        y1 = fp.y1;
+    }
+    RC(dev_ensure(ctx, &ctx->in, (size_t)w * 3 * h + 256));
+    if (ctx->debug_poison) CBV_HIP(ctx, hipMemsetAsync(ctx->in.p, 0xA5, (size_t)w * 3 * h, ctx->stream));
+    static const bool tm = getenv("CBV_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = tm ? now() : 0;
+    RC(rows_h2d(ctx, (u8*)ctx->in.p + (size_t)y0 * w * 3, bgr + (size_t)y0 * stride, stride, w * 3, y1 - y0));
+    const double t1 = tm ? now() : 0;
     Geom g = tight_geom(w, h);
     RC(dev_ensure(ctx, &ctx->a, (size_t)dw * dh * 3 + 256));
     RC(launch_warp(ctx, (const u8*)ctx->in.p, g, Minv, dw, dh, rot180, (u8*)ctx->a.p, dw * 3, (size_t)dw * dh * 3, nullptr, 1));
-    return download(ctx, ctx->a.p, out, dw * 3, dh, out_stride);
+    const double t2 = tm ? now() : 0;
+    RC(rows_d2h(ctx, out, out_stride, ctx->a.p, dw * 3, dh));
+    const double t3 = tm ? now() : 0;
+    CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (tm) fprintf(stderr, "warp: h2d %.1f launch %.1f d2h %.1f sync %.1f us (rows %d..%d)\n", t1 - t0, t2 - t1, t3 - t2, now() - t3, y0, y1);
+    return CBV_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -648,6 +735,9 @@ struct cbv_squares {
     std::vector<SquareDesc> descs;
     size_t plane_total = 0, mask_total = 0;
     DevBuf d_descs, d_masks, d_gray, d_ref, d_mean, d_var, d_stats, d_select, d_coef, d_stage, d_hough, d_retry;
+    DevBuf d_fast;  // one-call entry points: worklist (1 + 64 u32) | retry list (1 + 64 u32) | dflags (64 B) | second statistics set
+    DevBuf d_gray5; // cbv_squares_detect_changes with blur_k != 5: the squares as PieceDetector preprocesses them (k = 5)
+    std::vector<SquareDesc> descs_on_dev; // what d_descs holds (a host-image load re-uploads only when it differs)
     std::vector<u8> stage;
     bool has_ref = false, has_model = false;
     int coef_k = -1;
@@ -670,7 +760,8 @@ extern "C" void cbv_squares_destroy(cbv_squares* s)
         (void)hipSetDevice(s->ctx->device);
         (void)hipStreamSynchronize(s->ctx->stream);
     }
-    DevBuf* bufs[] = {&s->d_descs, &s->d_masks, &s->d_gray, &s->d_ref, &s->d_mean, &s->d_var, &s->d_stats, &s->d_select, &s->d_coef, &s->d_stage, &s->d_hough, &s->d_retry};
+    DevBuf* bufs[] = {&s->d_descs, &s->d_masks, &s->d_gray, &s->d_ref, &s->d_mean, &s->d_var, &s->d_stats, &s->d_select, &s->d_coef, &s->d_stage, &s->d_hough, &s->d_retry,
+                      &s->d_fast, &s->d_gray5};
     for (auto b : bufs) dev_free(b);
     delete s;
 }
@@ -774,6 +865,7 @@ extern "C" int cbv_squares_load(cbv_squares* s, const cbv_square_view* views, in
     RC(dev_ensure(ctx, &s->d_stage, total));
     CBV_HIP(ctx, hipMemcpyAsync(s->d_stage.p, s->stage.data(), total, hipMemcpyHostToDevice, ctx->stream));
     CBV_HIP(ctx, hipMemcpyAsync(s->d_descs.p, s->descs.data(), sizeof(SquareDesc) * n, hipMemcpyHostToDevice, ctx->stream));
+    s->descs_on_dev.clear();
     RC(launch_squares_preprocess(ctx, (const u8*)s->d_stage.p, 0, (const SquareDesc*)s->d_descs.p, n, (const int*)s->d_coef.p,
                                  s->blur_k, (u8*)s->d_gray.p, 0, 1));
     CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -803,6 +895,7 @@ extern "C" int cbv_squares_load_dev(cbv_squares* s, const void* dev_img, int w, 
     }
     CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     CBV_HIP(ctx, hipMemcpyAsync(s->d_descs.p, s->descs.data(), sizeof(SquareDesc) * n, hipMemcpyHostToDevice, ctx->stream));
+    s->descs_on_dev.clear();
     RC(launch_squares_preprocess(ctx, (const u8*)dev_img, 0, (const SquareDesc*)s->d_descs.p, n, (const int*)s->d_coef.p, s->blur_k,
                                  (u8*)s->d_gray.p, 0, 1));
     CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -914,6 +1007,340 @@ extern "C" int cbv_squares_hough(cbv_squares* s, const cbv_hough_params* prm, cb
                            (const u32*)s->d_retry.p, s->n));
     CBV_HIP(ctx, hipMemcpyAsync(out, s->d_hough.p, sizeof(cbv_hough_result) * s->n, hipMemcpyDeviceToHost, ctx->stream));
     CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CBV_OK;
+}
+
+// ---------------------------------------------------------------------------
+// one call per frame for the reference's own call pattern (game_session.py:124-161, calibrate_sensitivity.py:142-157):
+// the 64 squares are views of ONE host image (split_board of the warped board), so the image's bounding rows are
+// uploaded with one copy AT CALL TIME (nothing stale, no host pointer kept) and everything up to the per-square records
+// runs behind it with one wait at the end.
+// ---------------------------------------------------------------------------
+extern "C" int cbv_debug_poison(cbv_ctx* ctx, int on)
+{
+    if (!ctx) return CBV_ERR_ARG;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    ctx->debug_poison = on ? 1 : 0;
+    return CBV_OK;
+}
+
+static bool same_desc(const SquareDesc& a, const SquareDesc& b)
+{
+    return a.w == b.w && a.h == b.h && a.src_off == b.src_off && a.stride == b.stride && a.cn == b.cn && a.plane_off == b.plane_off &&
+           a.mask_off == b.mask_off;
+}
+
+// geometry + upload of the rows of `img` the ROIs cover + descriptors; leaves the stream with d_stage / d_descs ready.
+// `hst` (pinned, >= sizeof(SquareDesc) * n) stages the descriptors when they changed.
+static int squares_stage_host_image(cbv_squares* s, const cbv_host_image* img, const cbv_roi* rois, int n, int blur_k, u8* hst)
+{
+    cbv_ctx* ctx = s->ctx;
+    if (!img || !img->data || !rois || n <= 0 || n > CBV_MAX_SQUARES || (img->cn != 1 && img->cn != 3) || img->w <= 0 || img->h <= 0 ||
+        img->stride < img->w * img->cn)
+        return cbv_fail(ctx, CBV_ERR_ARG, "host image / roi arguments are invalid (n=%d)", n);
+    int ws[CBV_MAX_SQUARES], hs[CBV_MAX_SQUARES];
+    int y0 = img->h, y1 = 0;
+    for (int i = 0; i < n; i++) {
+        const cbv_roi& r = rois[i];
+        if (r.w <= 0 || r.h <= 0 || r.x0 < 0 || r.y0 < 0 || r.x0 + r.w > img->w || r.y0 + r.h > img->h)
+            return cbv_fail(ctx, CBV_ERR_ARG, "roi %d (%d,%d %dx%d) is outside the %dx%d image", i, r.x0, r.y0, r.w, r.h, img->w, img->h);
+        ws[i] = r.w;
+        hs[i] = r.h;
+        y0 = std::min(y0, r.y0);
+        y1 = std::max(y1, r.y0 + r.h);
+    }
+    RC(squares_set_geometry(s, ws, hs, n));
+    RC(squares_set_coef(s, blur_k));
+    // One contiguous copy of the rows the ROIs cover.  When the image's rows are padded or it is a crop of a wider frame,
+    // the bytes between its rows travel too as long as that at most doubles the copy (they lie inside the same
+    // allocation: between the first and the last byte of the image); a much wider pitch is gathered by a 2-D copy,
+    // which is several times slower per byte on this platform (tools/ubench_copy.hip).
+    const int rowb = img->w * img->cn;
+    const bool one_d = img->stride <= 2 * rowb;
+    const int pitch = one_d ? img->stride : rowb;
+    for (int i = 0; i < n; i++) {
+        s->descs[i].cn = img->cn;
+        s->descs[i].stride = pitch;
+        s->descs[i].src_off = (rois[i].y0 - y0) * pitch + rois[i].x0 * img->cn;
+    }
+    const size_t bytes = (size_t)pitch * (y1 - y0 - 1) + rowb;
+    RC(dev_ensure(ctx, &s->d_stage, bytes + 16)); // (+16: the 12-byte loads of the last pixels of the last row)
+    if (ctx->debug_poison) CBV_HIP(ctx, hipMemsetAsync(s->d_stage.p, 0xA5, bytes + 16, ctx->stream));
+    const u8* src = img->data + (size_t)y0 * img->stride;
+    if (one_d) CBV_HIP(ctx, hipMemcpyAsync(s->d_stage.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    else CBV_HIP(ctx, hipMemcpy2DAsync(s->d_stage.p, rowb, src, img->stride, rowb, y1 - y0, hipMemcpyHostToDevice, ctx->stream));
+    bool same = (int)s->descs_on_dev.size() == n;
+    for (int i = 0; same && i < n; i++) same = same_desc(s->descs_on_dev[i], s->descs[i]);
+    if (!same) {
+        memcpy(hst, s->descs.data(), sizeof(SquareDesc) * n);
+        CBV_HIP(ctx, hipMemcpyAsync(s->d_descs.p, hst, sizeof(SquareDesc) * n, hipMemcpyHostToDevice, ctx->stream));
+        s->descs_on_dev = s->descs;
+    }
+    return CBV_OK;
+}
+
+static int max_px_of(const cbv_squares* s)
+{
+    int m = 0;
+    for (const SquareDesc& d : s->descs) m = std::max(m, d.w * d.h);
+    return m;
+}
+
+extern "C" int cbv_squares_load_image(cbv_squares* s, const cbv_host_image* img, const cbv_roi* rois, int n, int blur_k)
+{
+    if (!s) return CBV_ERR_ARG;
+    cbv_ctx* ctx = s->ctx;
+    CBV_ENTER(ctx);
+    u8* hst;
+    RC(ctx_hstage(ctx, 65536, &hst));
+    RC(squares_stage_host_image(s, img, rois, n, blur_k, hst));
+    RC(launch_squares_preprocess(ctx, (const u8*)s->d_stage.p, 0, (const SquareDesc*)s->d_descs.p, n, (const int*)s->d_coef.p, s->blur_k,
+                                 (u8*)s->d_gray.p, 0, 1, max_px_of(s)));
+    CBV_HIP(ctx, hipStreamSynchronize(ctx->stream)); // the host image (and the pinned descriptors) are free again
+    return CBV_OK;
+}
+
+extern "C" int cbv_squares_set_ref_mask(cbv_squares* s, uint64_t mask)
+{
+    if (!s) return CBV_ERR_ARG;
+    cbv_ctx* ctx = s->ctx;
+    if (s->n == 0) return cbv_fail(ctx, CBV_ERR_STATE, "cbv_squares_set_ref_mask: no squares loaded");
+    CBV_ENTER(ctx);
+    RC(launch_squares_set_ref_mask(ctx, (const SquareDesc*)s->d_descs.p, s->n, (const u8*)s->d_gray.p, (u8*)s->d_ref.p, mask));
+    s->has_ref = true;
+    return CBV_OK; // asynchronous: later calls on this context are ordered behind it
+}
+
+// PieceDetector.detect_piece (piece_detector.py:289-345) for one square from its statistics and its HoughCircles
+// record, in the reference's arithmetic: np.std as an exact integer test, means and differences as float64
+// quotients, np.var of the ring means summed left to right like numpy does for fewer than eight elements.
+extern "C" int cbv_decide_piece(const cbv_sq_stats* st, const cbv_hough_result* hg, int w, int h, double circle_threshold,
+                                cbv_piece_result* out)
+{
+    if (!st || !out) return CBV_ERR_ARG;
+    out->has_piece = 0;
+    out->method = CBV_METHOD_NONE;
+    out->cx = out->cy = out->radius = 0;
+    out->confidence = 0.0;
+    out->center_border_diff = 0.0;
+    const long long n = st->n, sm = st->sum;
+    if (n * (long long)st->sumsq - sm * sm < 225ll * n * n) return CBV_OK; // np.std(gray) < 15: nothing else is tried
+    if (hg && (hg->flags & CBV_HOUGH_OVERFLOW)) return CBV_ERR_UNSUPPORTED; // never passed on as HoughCircles' answer
+    if (hg && hg->found) {
+        out->has_piece = 1;
+        out->method = hg->kind == 2 ? CBV_METHOD_TOWER_TOP : CBV_METHOD_HOUGH;
+        out->cx = (int)hg->cx; // int(np.float32): toward zero
+        out->cy = (int)hg->cy;
+        out->radius = (int)hg->r;
+        out->confidence = hg->kind == 2 ? 0.75 : 0.9;
+        return CBV_OK;
+    }
+    const double zero = 0.0;
+    const double cm = st->center_cnt ? (double)st->center_sum / (double)st->center_cnt : zero / zero; // np.mean of nothing is nan
+    const double bm = st->border_cnt ? (double)st->border_sum / (double)st->border_cnt : zero / zero;
+    const double diff = fabs(cm - bm);
+    out->center_border_diff = diff;
+    const int md = w < h ? w : h;
+    if (diff > 40) {
+        out->has_piece = 1;
+        out->method = CBV_METHOD_CENTER_DIFF;
+        out->cx = w / 2;
+        out->cy = h / 2;
+        out->radius = md / 3;
+        out->confidence = diff / 80 < 1.0 ? diff / 80 : 1.0;
+        return CBV_OK;
+    }
+    double rm[4];
+    int nr = 0;
+    for (int k = 0; k < 4; k++)
+        if (st->ring_cnt[k] > 0) rm[nr++] = (double)st->ring_sum[k] / (double)st->ring_cnt[k];
+    double symmetry = 0.0;
+    if (nr >= 2) {
+        double sum = 0;
+        for (int k = 0; k < nr; k++) sum = sum + rm[k];
+        const double mean = sum / nr;
+        double sq = 0;
+        for (int k = 0; k < nr; k++) {
+            const double x = rm[k] - mean;
+            sq = sq + x * x;
+        }
+        const double var = sq / nr;
+        symmetry = var / 500 < 1.0 ? var / 500 : 1.0;
+    }
+    if (symmetry > circle_threshold) {
+        out->has_piece = 1;
+        out->method = CBV_METHOD_SYMMETRY;
+        out->cx = w / 2;
+        out->cy = h / 2;
+        out->radius = md / 3;
+        out->confidence = symmetry;
+    }
+    return CBV_OK;
+}
+
+// device scratch of the one-call entry points: worklist | retry list | then everything that travels back to the host as
+// ONE copy: gate flags | statistics | second statistics set (k = 5 planes) | HoughCircles records
+struct FastLayout {
+    u32* work;
+    u32* retry;
+    u8* out;       // start of the block that is copied back
+    u8* dflags;
+    cbv_sq_stats* stats;
+    cbv_sq_stats* stats5;
+    cbv_hough_result* hough;
+    size_t o_flags, o_stats, o_stats5, o_hough, out_bytes; // offsets inside the block
+};
+static int fast_layout(cbv_squares* s, FastLayout* L)
+{
+    const size_t o_retry = 512, o_out = 1024;
+    L->o_flags = 0;
+    L->o_stats = 64;
+    L->o_stats5 = L->o_stats + sizeof(cbv_sq_stats) * CBV_MAX_SQUARES;
+    L->o_hough = L->o_stats5 + sizeof(cbv_sq_stats) * CBV_MAX_SQUARES;
+    L->out_bytes = L->o_hough + sizeof(cbv_hough_result) * CBV_MAX_SQUARES;
+    RC(dev_ensure(s->ctx, &s->d_fast, o_out + L->out_bytes));
+    u8* b = (u8*)s->d_fast.p;
+    L->work = (u32*)b;
+    L->retry = (u32*)(b + o_retry);
+    L->out = b + o_out;
+    L->dflags = L->out + L->o_flags;
+    L->stats = (cbv_sq_stats*)(L->out + L->o_stats);
+    L->stats5 = (cbv_sq_stats*)(L->out + L->o_stats5);
+    L->hough = (cbv_hough_result*)(L->out + L->o_hough);
+    return CBV_OK;
+}
+
+extern "C" int cbv_squares_detect_all(cbv_squares* s, const cbv_host_image* img, const cbv_roi* rois, int n,
+                                      const cbv_detect_params* prm, cbv_piece_result* out)
+{
+    if (!s) return CBV_ERR_ARG;
+    cbv_ctx* ctx = s->ctx;
+    if (!prm || !out) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_squares_detect_all: null argument");
+    CBV_ENTER(ctx);
+    u8* hst;
+    const size_t o_back = 4096; // the descriptors are staged in front of it
+    RC(ctx_hstage(ctx, 65536, &hst));
+    RC(squares_stage_host_image(s, img, rois, n, 5, hst));
+    HoughCfg hc;
+    RC(hough_cfg(ctx, &prm->hough, s->descs, &hc));
+    FastLayout L;
+    RC(fast_layout(s, &L));
+    CBV_HIP(ctx, hipMemsetAsync(s->d_fast.p, 0, 1024, ctx->stream)); // worklist and retry counters
+    DetectMasks dm;
+    dm.has_ref = s->has_ref ? prm->has_ref : 0;
+    dm.cached = prm->cached;
+    dm.check = prm->check;
+    dm.check_given = prm->check_given;
+    dm.use_delta = prm->use_delta;
+    dm.change_threshold = prm->change_threshold;
+    dm.dflags = L.dflags;
+    // preprocess + statistics (+ |gray - reference|) + the gate, one launch; HoughCircles over the squares it listed
+    RC(launch_squares_pre5_stats(ctx, (const u8*)s->d_stage.p, 0, (const SquareDesc*)s->d_descs.p, n, (u8*)s->d_gray.p, 0, nullptr, nullptr,
+                                 (const u8*)s->d_masks.p, 0.f, L.stats, 1, nullptr, 1, L.work, L.hough, max_px_of(s), (const u8*)s->d_ref.p, &dm));
+    RC(launch_hough(ctx, (const SquareDesc*)s->d_descs.p, n, (const u8*)s->d_gray.p, 0, hc, L.hough, nullptr, L.work, 1, L.retry, 0));
+    RC(launch_hough_second(ctx, (const SquareDesc*)s->d_descs.p, n, (const u8*)s->d_gray.p, 0, hc, L.hough, nullptr, L.retry, n));
+    CBV_HIP(ctx, hipMemcpyAsync(hst + o_back, L.out, L.out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const cbv_sq_stats* st = (const cbv_sq_stats*)(hst + o_back + L.o_stats);
+    const cbv_hough_result* hg = (const cbv_hough_result*)(hst + o_back + L.o_hough);
+    const u8* fl = hst + o_back + L.o_flags;
+    for (int i = 0; i < n; i++) {
+        cbv_piece_result r;
+        memset(&r, 0, sizeof(r));
+        if (fl[i] & 4) { // detect_piece is evaluated for this square
+            const bool hough_ran = (fl[i] & 8) != 0;
+            if (cbv_decide_piece(&st[i], hough_ran ? &hg[i] : nullptr, s->descs[i].w, s->descs[i].h, prm->circle_threshold, &r) != CBV_OK)
+                return cbv_fail(ctx, CBV_ERR_UNSUPPORTED, "HoughCircles candidate list overflowed (more accumulator maxima than the second pass holds in a "
+                                "%dx%d square)", s->descs[i].w, s->descs[i].h);
+        }
+        r.changed = fl[i] & 1;
+        r.should_process = (fl[i] >> 1) & 1;
+        r.evaluated = (fl[i] >> 2) & 1;
+        out[i] = r;
+    }
+    return CBV_OK;
+}
+
+extern "C" int cbv_squares_detect_changes(cbv_squares* s, const cbv_host_image* img, const cbv_roi* rois, int n, int blur_k,
+                                          const cbv_change_params* prm, cbv_change_result* out)
+{
+    if (!s) return CBV_ERR_ARG;
+    cbv_ctx* ctx = s->ctx;
+    if (!prm || !out) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_squares_detect_changes: null argument");
+    if (!s->has_model) return cbv_fail(ctx, CBV_ERR_STATE, "cbv_squares_detect_changes: not calibrated");
+    CBV_ENTER(ctx);
+    u8* hst;
+    const size_t o_back = 4096, o_wk = 40960;
+    RC(ctx_hstage(ctx, 65536, &hst));
+    const int old_n = s->n;
+    RC(squares_stage_host_image(s, img, rois, n, blur_k, hst));
+    if (!s->has_model || s->n != old_n) return cbv_fail(ctx, CBV_ERR_STATE, "cbv_squares_detect_changes: the squares' geometry changed since calibrate");
+    FastLayout L;
+    RC(fast_layout(s, &L));
+    const int mpx = max_px_of(s);
+    const bool five = s->blur_k == 5;
+    if (five) {
+        RC(launch_squares_pre5_stats(ctx, (const u8*)s->d_stage.p, 0, (const SquareDesc*)s->d_descs.p, n, (u8*)s->d_gray.p, 0, (const float*)s->d_mean.p,
+                                     (const float*)s->d_var.p, (const u8*)s->d_masks.p, (float)prm->z_threshold, L.stats, 1, nullptr, 0, nullptr, nullptr,
+                                     mpx));
+    } else {
+        // the detector's own blur for the background model, and the squares as PieceDetector preprocesses them (k = 5)
+        // for the is_circular test of the squares that changed
+        RC(launch_squares_preprocess(ctx, (const u8*)s->d_stage.p, 0, (const SquareDesc*)s->d_descs.p, n, (const int*)s->d_coef.p, s->blur_k,
+                                     (u8*)s->d_gray.p, 0, 1, mpx));
+        RC(launch_squares_stats(ctx, (const SquareDesc*)s->d_descs.p, n, (const u8*)s->d_gray.p, 0, nullptr, (const float*)s->d_mean.p,
+                                (const float*)s->d_var.p, (const u8*)s->d_masks.p, (float)prm->z_threshold, L.stats, 1));
+        RC(dev_ensure(ctx, &s->d_gray5, s->plane_total));
+        RC(launch_squares_pre5_stats(ctx, (const u8*)s->d_stage.p, 0, (const SquareDesc*)s->d_descs.p, n, (u8*)s->d_gray5.p, 0, nullptr, nullptr,
+                                     (const u8*)s->d_masks.p, 0.f, L.stats5, 1, nullptr, 0, nullptr, nullptr, mpx));
+    }
+    CBV_HIP(ctx, hipMemcpyAsync(hst + o_back + L.o_stats, L.stats, sizeof(cbv_sq_stats) * CBV_MAX_SQUARES * (five ? 1 : 2), hipMemcpyDeviceToHost, ctx->stream));
+    CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const cbv_sq_stats* st = (const cbv_sq_stats*)(hst + o_back + L.o_stats);
+    const cbv_sq_stats* st5 = five ? st : (const cbv_sq_stats*)(hst + o_back + L.o_stats5);
+    // change_detector.py:124-150: squares of the selection whose share of changed pixels reaches 5 %
+    u32* work = (u32*)(hst + o_wk);
+    int nwork = 0;
+    for (int i = 0; i < n; i++) {
+        cbv_change_result r;
+        memset(&r, 0, sizeof(r));
+        r.z_max = st[i].z_max;
+        r.z_count = st[i].z_count;
+        r.n = st[i].n;
+        if ((prm->select >> i) & 1ull) {
+            const double pct = ((double)st[i].z_count / (double)st[i].n) * 100.0;
+            if (!(pct < 5.0)) {
+                r.in_result = 1;
+                r.intensity = pct > 75.0 ? 3 : (pct > 15.0 ? 2 : 1);
+                const long long nn = st5[i].n, sm = st5[i].sum;
+                if (!(nn * (long long)st5[i].sumsq - sm * sm < 225ll * nn * nn)) work[1 + nwork++] = (u32)i; // HoughCircles runs on it
+            }
+        }
+        out[i] = r;
+    }
+    const cbv_hough_result* hg = nullptr;
+    if (nwork) {
+        HoughCfg hc;
+        RC(hough_cfg(ctx, &prm->hough, s->descs, &hc));
+        work[0] = (u32)nwork;
+        CBV_HIP(ctx, hipMemcpyAsync(L.work, work, sizeof(u32) * (1 + nwork), hipMemcpyHostToDevice, ctx->stream));
+        CBV_HIP(ctx, hipMemsetAsync(L.retry, 0, sizeof(u32), ctx->stream));
+        const u8* g5 = five ? (const u8*)s->d_gray.p : (const u8*)s->d_gray5.p;
+        RC(launch_hough(ctx, (const SquareDesc*)s->d_descs.p, n, g5, 0, hc, L.hough, nullptr, L.work, 1, L.retry, 0));
+        RC(launch_hough_second(ctx, (const SquareDesc*)s->d_descs.p, n, g5, 0, hc, L.hough, nullptr, L.retry, n));
+        CBV_HIP(ctx, hipMemcpyAsync(hst + o_back + L.o_hough, L.hough, sizeof(cbv_hough_result) * n, hipMemcpyDeviceToHost, ctx->stream));
+        CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        hg = (const cbv_hough_result*)(hst + o_back + L.o_hough);
+    }
+    for (int i = 0; i < n; i++) {
+        if (!out[i].in_result) continue;
+        bool ran = false;
+        for (int k = 0; k < nwork && !ran; k++) ran = work[1 + k] == (u32)i;
+        cbv_piece_result pr;
+        if (cbv_decide_piece(&st5[i], ran ? &hg[i] : nullptr, s->descs[i].w, s->descs[i].h, prm->circle_threshold, &pr) != CBV_OK)
+            return cbv_fail(ctx, CBV_ERR_UNSUPPORTED, "HoughCircles candidate list overflowed in a %dx%d square", s->descs[i].w, s->descs[i].h);
+        out[i].is_circular = pr.has_piece;
+    }
     return CBV_OK;
 }
 
@@ -1193,33 +1620,8 @@ extern "C" int cbv_pipeline_configure(cbv_pipeline* p, const cbv_pipeline_config
     // Minv (a projective map keeps the square convex while W > 0 on it: its four corners bound it), + 3 px for the
     // 1/32-px rounding and the bilinear taps
     p->use_region = false;
-    if (cfg->enhance_region && !p->keep_enhanced && sharpen_region_ok(cfg->enhance.sharpen_kernel)) {
-        double lo[2] = {1e30, 1e30}, hi[2] = {-1e30, -1e30};
-        bool ok = true;
-        for (int k = 0; k < 4 && ok; k++) {
-            const double dx = (k & 1) ? S - 1 : 0, dy = (k & 2) ? S - 1 : 0;
-            const double W = p->Minv[6] * dx + p->Minv[7] * dy + p->Minv[8];
-            if (!(W > 1e-12)) ok = false;
-            else {
-                const double c[2] = {(p->Minv[0] * dx + p->Minv[1] * dy + p->Minv[2]) / W, (p->Minv[3] * dx + p->Minv[4] * dy + p->Minv[5]) / W};
-                for (int a = 0; a < 2; a++) {
-                    lo[a] = std::min(lo[a], c[a]);
-                    hi[a] = std::max(hi[a], c[a]);
-                }
-            }
-        }
-        if (ok && lo[0] > -1e8 && lo[1] > -1e8 && hi[0] < 1e8 && hi[1] < 1e8) { // (the casts below stay inside int)
-            PxRect r = {(int)floor(lo[0]) - 3, (int)floor(lo[1]) - 3, (int)ceil(hi[0]) + 4, (int)ceil(hi[1]) + 4};
-            r.x0 = std::max(r.x0, 0);
-            r.y0 = std::max(r.y0, 0);
-            r.x1 = std::min(r.x1, p->w);
-            r.y1 = std::min(r.y1, p->h);
-            if (r.x1 > r.x0 && r.y1 > r.y0) {
-                p->region = r;
-                p->use_region = true;
-            }
-        }
-    }
+    if (cfg->enhance_region && !p->keep_enhanced && sharpen_region_ok(cfg->enhance.sharpen_kernel))
+        p->use_region = warp_footprint(p->Minv, S, S, p->w, p->h, &p->region);
     if (p->warped) (void)hipFree(p->warped);
     if (p->enhanced) (void)hipFree(p->enhanced);
     p->warped = p->enhanced = nullptr;
@@ -1340,7 +1742,7 @@ extern "C" int cbv_pipeline_upload(cbv_pipeline* p, int slot, const uint8_t* bgr
     cbv_ctx* ctx = p->ctx;
     CBV_ENTER(ctx);
     RC(join_scan(p)); // lanes and scan of the last run
-    CBV_HIP(ctx, hipMemcpy2DAsync(p->frames + p->g.frame_stride * slot, p->w * 3, bgr, stride, p->w * 3, p->h, hipMemcpyHostToDevice, ctx->stream));
+    RC(rows_h2d(ctx, p->frames + p->g.frame_stride * slot, bgr, stride, p->w * 3, p->h));
     CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return CBV_OK;
 }

@@ -116,7 +116,16 @@ struct cbv_ctx {
     // for their whole call (CBV_ENTER), so calls from several threads on one context serialise instead of corrupting it.
     std::recursive_mutex mu;
     bool hough_lds_raised = false; // k_hough's dynamic-LDS limit was raised for this device
+
+    // pinned staging for the small records the one-frame-per-call (class API) entry points move in either direction
+    // (square descriptors, worklists, statistics, HoughCircles results): a copy from / to pinned memory is one DMA
+    // (12 us for 16 KB against 26 us through the runtime's pageable path); guarded by `mu`, and every call that uses
+    // it synchronises before it returns
+    u8* h_stage = nullptr;
+    size_t h_stage_cap = 0;
+    int debug_poison = 0; // tests: fill partially uploaded staging buffers with 0xA5 first (cbv_debug_poison)
 };
+int ctx_hstage(cbv_ctx* ctx, size_t bytes, u8** p);
 
 extern thread_local std::string g_cbv_err;
 int cbv_fail(cbv_ctx* ctx, int code, const char* fmt, ...);
@@ -303,12 +312,23 @@ struct SquareDesc {
     int mask_off;  // byte offset into the mask table
     int pad;
 };
+// detect_all_pieces' per-square gate for the class API (one frame), evaluated by thread 0 of the statistics kernels:
+// bit i of the sets = square i.  dflags == null: not a class-API launch.
+struct DetectMasks {
+    u64 has_ref = 0;     // pos in reference_squares
+    u64 cached = 0;      // pos in cached_results
+    u64 check = 0;       // pos in squares_to_check
+    int check_given = 0; // squares_to_check is not None
+    int use_delta = 1;
+    double change_threshold = 25.0;
+    u8* dflags = nullptr; // out, per square: 1 has_changed_visual, 2 should_process, 4 detect_piece is evaluated, 8 std >= 15
+};
 int launch_squares_preprocess(cbv_ctx* ctx, const u8* src, size_t src_frame_stride, const SquareDesc* descs, int n,
                               const int* coef_dev, int blur_k, u8* gray, size_t gray_frame_stride, int batch, int max_px = 0);
 int launch_squares_stats(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, size_t gray_frame_stride,
                          const u8* ref, const float* mean, const float* var, const u8* masks, float z_thresh,
                          cbv_sq_stats* out, int batch, u8* decisions = nullptr, int want_hough = 0, u32* hough_work = nullptr,
-                         cbv_hough_result* hough_out = nullptr);
+                         cbv_hough_result* hough_out = nullptr, const DetectMasks* dm = nullptr);
 
 // HoughCircles per square (k_hough.hip).  off_* / max_* are filled by launch_hough.
 struct HoughCfg {
@@ -336,12 +356,13 @@ int launch_hough_second(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* 
 int launch_squares_pre5_stats(cbv_ctx* ctx, const u8* src, size_t src_frame_stride, const SquareDesc* descs, int n, u8* gray,
                               size_t gray_frame_stride, const float* mean, const float* var, const u8* masks, float z_thresh,
                               cbv_sq_stats* out, int batch, u8* decisions, int want_hough, u32* hough_work,
-                              cbv_hough_result* hough_out, int max_px);
+                              cbv_hough_result* hough_out, int max_px, const u8* ref = nullptr, const DetectMasks* dm = nullptr);
 int launch_squares_calibrate(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, float* mean, float* var,
                              float init_var, const u8* select);
 int launch_squares_ema(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, float* mean, float* var,
                        double alpha, const u8* select);
 int launch_squares_set_ref(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, u8* ref, const u8* select);
+int launch_squares_set_ref_mask(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, u8* ref, u64 mask);
 
 struct ScanParams {
     int n;               // squares

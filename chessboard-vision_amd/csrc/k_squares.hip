@@ -229,7 +229,7 @@ __device__ __forceinline__ void sq_accum_px(SqAccum& A, int gv, u32 mk, bool has
 __device__ __forceinline__ void sq_accum_finish(SqAccum& A, u32* acc, float* zm, int* nanf_, int n, bool has_model,
                                                 cbv_sq_stats* __restrict__ out, int nsq, u8* __restrict__ decisions,
                                                 int want_hough, u32* __restrict__ hough_work,
-                                                cbv_hough_result* __restrict__ hough_out)
+                                                cbv_hough_result* __restrict__ hough_out, const DetectMasks dm = DetectMasks())
 {
 #pragma unroll
     for (int k = 0; k < 16; k++) {
@@ -259,6 +259,25 @@ __device__ __forceinline__ void sq_accum_finish(SqAccum& A, u32* acc, float* zm,
         for (int k = 1; k < (int)(blockDim.x >> 6); k++) z = fmaxf(z, zm[k]);
         st.z_max = nanf_[0] ? __builtin_nanf("") : z;
         out[(size_t)blockIdx.z * nsq + blockIdx.x] = st;
+        if (dm.dflags) {
+            // detect_all_pieces' per-square gate (piece_detector.py:367-395) for the class API, one frame: which squares
+            // changed against their reference, which are processed, and which of those need HoughCircles (the reference
+            // runs it on every square it evaluates whose std is >= 15, before the two statistics-based tests)
+            const u64 bit = 1ull << blockIdx.x;
+            const bool has_ref = (dm.has_ref & bit) != 0, cached = (dm.cached & bit) != 0;
+            const bool changed = !has_ref || (double)st.sad_ref / (double)st.n > dm.change_threshold; // np.mean(diff) > thr
+            bool should = dm.check_given && (dm.check & bit);
+            if (!should && (!dm.check_given || dm.use_delta)) should = !cached || changed;
+            const bool evaluated = should || !cached;
+            const long long nn = st.n, sm = st.sum;
+            const bool std_ok = !(nn * (long long)st.sumsq - sm * sm < 225ll * nn * nn);
+            dm.dflags[blockIdx.x] = (u8)((changed ? 1u : 0u) | (should ? 2u : 0u) | (evaluated ? 4u : 0u) | (std_ok ? 8u : 0u));
+            cbv_hough_result r;
+            memset(&r, 0, sizeof(r));
+            r.flags = CBV_HOUGH_SKIPPED;
+            if (want_hough && evaluated && std_ok) hough_work[1 + atomicAdd(&hough_work[0], 1u)] = blockIdx.x;
+            else if (hough_out) hough_out[blockIdx.x] = r;
+        }
         if (decisions) {
             // the frame-parallel part of both detectors' decisions, so the sequential scan only does integer work:
             // bit0 detect_piece(square), bits 1-3 ChangeDetector class (in dict / PARCIAL / TOTAL),
@@ -290,7 +309,7 @@ __global__ __launch_bounds__(256) void k_squares_stats(const SquareDesc* __restr
                                                         const float* __restrict__ var, const u8* __restrict__ masks,
                                                         float z_thresh, cbv_sq_stats* __restrict__ out, int nsq,
                                                         u8* __restrict__ decisions, int want_hough, u32* __restrict__ hough_work,
-                                                        cbv_hough_result* __restrict__ hough_out)
+                                                        cbv_hough_result* __restrict__ hough_out, const DetectMasks dm)
 {
     __shared__ u32 acc[20];
     __shared__ float zm[4];
@@ -308,7 +327,7 @@ __global__ __launch_bounds__(256) void k_squares_stats(const SquareDesc* __restr
     for (int i = threadIdx.x; i < n; i += blockDim.x)
         sq_accum_px(A, g[i], m[i], ref != nullptr, ref ? (int)ref[d.plane_off + i] : 0, mean != nullptr,
                     mean ? mean[d.plane_off + i] : 0.f, mean ? var[d.plane_off + i] : 1.f, z_thresh);
-    sq_accum_finish(A, acc, zm, nanf_, n, mean != nullptr, out, nsq, decisions, want_hough, hough_work, hough_out);
+    sq_accum_finish(A, acc, zm, nanf_, n, mean != nullptr, out, nsq, decisions, want_hough, hough_work, hough_out, dm);
 }
 
 // preprocess (k = 5) and statistics of the pipeline in one pass: the statistics are sums over the plane the blur
@@ -322,7 +341,8 @@ __global__ __launch_bounds__(NT) void k_squares_pre5_stats(const u8* __restrict_
                                                              const float* __restrict__ var, const u8* __restrict__ masks,
                                                              float z_thresh, cbv_sq_stats* __restrict__ out, int nsq,
                                                              u8* __restrict__ decisions, int want_hough,
-                                                             u32* __restrict__ hough_work, cbv_hough_result* __restrict__ hough_out)
+                                                             u32* __restrict__ hough_work, cbv_hough_result* __restrict__ hough_out,
+                                                             const u8* __restrict__ ref, const DetectMasks dm)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     __shared__ u32 acc[20];
@@ -383,6 +403,8 @@ __global__ __launch_bounds__(NT) void k_squares_pre5_stats(const u8* __restrict_
     const u8* m = masks + d.mask_off;
     const float* mp = mean ? mean + d.plane_off : nullptr;
     const float* vp = mean ? var + d.plane_off : nullptr;
+    // class API: sum |gray - reference| of squares that have one (piece_detector.py:82-93)
+    const u8* rp = (ref && ((dm.has_ref >> blockIdx.x) & 1ull)) ? ref + d.plane_off : nullptr;
     SqAccum A;
     sq_accum_init(A);
     for (int y = ty; y < h; y += NT / 16) {
@@ -392,26 +414,27 @@ __global__ __launch_bounds__(NT) void k_squares_pre5_stats(const u8* __restrict_
             const int gv = (int)((a2 + (1u << 15)) >> 16);
             const int i = y * w + x;
             outp[i] = (u8)gv;
-            sq_accum_px(A, gv, m[i], false, 0, mp != nullptr, mp ? mp[i] : 0.f, mp ? vp[i] : 1.f, z_thresh);
+            sq_accum_px(A, gv, m[i], rp != nullptr, rp ? (int)rp[i] : 0, mp != nullptr, mp ? mp[i] : 0.f, mp ? vp[i] : 1.f, z_thresh);
         }
     }
-    sq_accum_finish(A, acc, zm, nanf_, n, mp != nullptr, out, nsq, decisions, want_hough, hough_work, hough_out);
+    sq_accum_finish(A, acc, zm, nanf_, n, mp != nullptr, out, nsq, decisions, want_hough, hough_work, hough_out, dm);
 }
 
 int launch_squares_pre5_stats(cbv_ctx* ctx, const u8* src, size_t src_frame_stride, const SquareDesc* descs, int n, u8* gray,
                               size_t gray_frame_stride, const float* mean, const float* var, const u8* masks, float z_thresh,
                               cbv_sq_stats* out, int batch, u8* decisions, int want_hough, u32* hough_work,
-                              cbv_hough_result* hough_out, int max_px)
+                              cbv_hough_result* hough_out, int max_px, const u8* ref, const DetectMasks* dmp)
 {
+    const DetectMasks dm = dmp ? *dmp : DetectMasks();
     if (max_px <= 0 || max_px > CBV_MAX_SQUARE_DIM * CBV_MAX_SQUARE_DIM) max_px = CBV_MAX_SQUARE_DIM * CBV_MAX_SQUARE_DIM;
     const size_t lds = (size_t)((max_px + 15) & ~15) + 2 * (size_t)max_px;
     prof_begin(ctx, CBV_K_SQUARES);
     if ((long long)n * batch <= 2 * ctx->num_cus)
         hipLaunchKernelGGL(k_squares_pre5_stats<1024>, dim3(n, 1, batch), dim3(1024), lds, ctx->stream, src, src_frame_stride, descs, gray,
-                           gray_frame_stride, mean, var, masks, z_thresh, out, n, decisions, want_hough, hough_work, hough_out);
+                           gray_frame_stride, mean, var, masks, z_thresh, out, n, decisions, want_hough, hough_work, hough_out, ref, dm);
     else
         hipLaunchKernelGGL(k_squares_pre5_stats<256>, dim3(n, 1, batch), dim3(256), lds, ctx->stream, src, src_frame_stride, descs, gray,
-                           gray_frame_stride, mean, var, masks, z_thresh, out, n, decisions, want_hough, hough_work, hough_out);
+                           gray_frame_stride, mean, var, masks, z_thresh, out, n, decisions, want_hough, hough_work, hough_out, ref, dm);
     prof_end(ctx, CBV_K_SQUARES);
     CBV_HIP(ctx, hipGetLastError());
     return CBV_OK;
@@ -420,11 +443,12 @@ int launch_squares_pre5_stats(cbv_ctx* ctx, const u8* src, size_t src_frame_stri
 int launch_squares_stats(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, size_t gray_frame_stride,
                          const u8* ref, const float* mean, const float* var, const u8* masks, float z_thresh,
                          cbv_sq_stats* out, int batch, u8* decisions, int want_hough, u32* hough_work,
-                         cbv_hough_result* hough_out)
+                         cbv_hough_result* hough_out, const DetectMasks* dmp)
 {
+    const DetectMasks dm = dmp ? *dmp : DetectMasks();
     prof_begin(ctx, CBV_K_SQUARES);
     hipLaunchKernelGGL(k_squares_stats, dim3(n, 1, batch), dim3(256), 0, ctx->stream, descs, gray, gray_frame_stride,
-                       ref, mean, var, masks, z_thresh, out, n, decisions, want_hough, hough_work, hough_out);
+                       ref, mean, var, masks, z_thresh, out, n, decisions, want_hough, hough_work, hough_out, dm);
     prof_end(ctx, CBV_K_SQUARES);
     CBV_HIP(ctx, hipGetLastError());
     return CBV_OK;
@@ -509,6 +533,22 @@ int launch_squares_ema(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* g
     // (1 - self.alpha) and self.alpha are python doubles turned float32 by numpy (weak scalars)
     float one_minus = (float)(1.0 - alpha), a = (float)alpha;
     hipLaunchKernelGGL(k_squares_ema, dim3(n), dim3(256), 0, ctx->stream, descs, gray, mean, var, one_minus, a, select);
+    CBV_HIP(ctx, hipGetLastError());
+    return CBV_OK;
+}
+
+// reference_squares[pos] = gray.copy() for the squares of a 64-bit set: the set rides in the kernel arguments, so the
+// launch needs no host buffer (and no synchronisation on the host's side)
+__global__ void k_squares_set_ref_mask(const SquareDesc* __restrict__ descs, const u8* __restrict__ gray, u8* __restrict__ ref, u64 mask)
+{
+    if (!((mask >> blockIdx.x) & 1ull)) return;
+    const SquareDesc d = descs[blockIdx.x];
+    for (int i = threadIdx.x; i < d.w * d.h; i += blockDim.x) ref[d.plane_off + i] = gray[d.plane_off + i];
+}
+
+int launch_squares_set_ref_mask(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, u8* ref, u64 mask)
+{
+    hipLaunchKernelGGL(k_squares_set_ref_mask, dim3(n), dim3(256), 0, ctx->stream, descs, gray, ref, mask);
     CBV_HIP(ctx, hipGetLastError());
     return CBV_OK;
 }

@@ -16,7 +16,7 @@ import os
 import numpy as np
 
 from . import _native as N
-from ._squares import GRAY, REF, PlaneDict, SquareSet
+from ._squares import GRAY, REF, PlaneDict, SquareSet, plan_of
 
 SETTINGS_FILE = "piece_detector_settings.json"
 
@@ -39,6 +39,7 @@ class PieceDetectorHIP:
         self.reference_squares = PlaneDict(self._state, REF)
         self.cached_results = {}
         self.change_threshold = 25
+        self._prm = N.DetectParams()
 
     def load_settings(self):
         """Radii from piece_detector_settings.json in the cwd (piece_detector.py:52-68)."""
@@ -157,9 +158,18 @@ class PieceDetectorHIP:
     def update_references(self, squares_dict):
         """piece_detector.py:447-453"""
         self._load_state(squares_dict)
-        self._state.set_ref(list(squares_dict.keys()))
+        lay = self._state._layout
+        if lay is not None:
+            self._state.set_ref_mask(lay.mask(squares_dict.keys()))  # asynchronous, the set rides in the launch
+        else:
+            self._state.set_ref(list(squares_dict.keys()))
         self.reference_squares._mark(squares_dict.keys())
         self.cached_results.clear()
+
+    def _fill_hough(self, hp):
+        k = self._hough_kwargs()
+        hp.dp, hp.param1, hp.param2 = float(k["dp"]), float(k["param1"]), float(k["param2"])
+        hp.min_radius_ratio, hp.max_radius_ratio = float(k["min_radius_ratio"]), float(k["max_radius_ratio"])
 
     def _load_state(self, squares_dict):
         keys = self._state.keys if (self._state.keys and set(squares_dict.keys()) <= set(self._state.keys)) else None
@@ -181,7 +191,73 @@ class PieceDetectorHIP:
         return sum(history) / len(history) >= self.min_presence
 
     def detect_all_pieces(self, squares_dict, use_smoothing=True, use_delta=True, squares_to_check=None):
-        """piece_detector.py:348-440.  Returns (results, visual_changes)."""
+        """piece_detector.py:348-440.  Returns (results, visual_changes).
+
+        When the squares are views of one image (split_board's dict) the device half is ONE library call
+        (cbv_squares_detect_all: upload of the board at call time, preprocess, |gray - reference|, the should_process
+        gate, HoughCircles on the squares the reference would run it on, detect_piece) and the loop below only does
+        what the reference's class keeps on the host: cache, history, smoothing, which references to refresh."""
+        results, visual_changes = {}, set()
+        if not squares_dict:
+            return results, visual_changes
+        plan = plan_of(squares_dict)
+        if plan is None or (self._state.keys and plan[1].keys != self._state.keys and set(plan[1].keys) < set(self._state.keys)):
+            return self._detect_all_pieces_views(squares_dict, use_smoothing, use_delta, squares_to_check)
+        img, lay = plan
+        state, refs, cached, hist_all = self._state, self.reference_squares, self.cached_results, self.detection_history
+        if state.adopt(lay):
+            refs.clear()  # geometry changed: the device planes are void
+        prm = self._prm
+        prm.change_threshold = float(self.change_threshold)
+        prm.circle_threshold = float(self.circle_threshold)
+        self._fill_hough(prm.hough)
+        prm.has_ref = lay.mask(refs._valid)
+        prm.cached = lay.mask(cached)
+        prm.check_given = 0 if squares_to_check is None else 1
+        prm.check = 0 if squares_to_check is None else lay.mask(squares_to_check)
+        prm.use_delta = 1 if use_delta else 0
+        rows = state.detect_all(img, lay, prm)
+        hs, mp, names = self.history_size, self.min_presence, N.METHOD_NAMES
+        refresh, refreshed = 0, []
+        for pos, bit, (has_piece, method, changed, should, evaluated, cx, cy, radius, conf, diff) in zip(lay.keys, lay.bits, rows):
+            if changed:
+                visual_changes.add(pos)
+            if evaluated:
+                if has_piece:
+                    raw = {"has_piece": True, "confidence": conf, "center": (cx, cy), "radius": radius, "method": names[method],
+                           "center_border_diff": diff, "is_ellipse": False, "axes": None}
+                else:
+                    raw = {"has_piece": False, "confidence": conf, "center": None, "radius": None, "method": None,
+                           "center_border_diff": diff, "is_ellipse": False, "axes": None}
+                cached[pos] = raw.copy()
+            else:
+                raw = cached[pos].copy()
+            raw_has = raw["has_piece"]
+            hist = hist_all.get(pos)
+            if hist is None:
+                hist = hist_all[pos] = []
+            hist.append(raw_has)
+            if len(hist) > hs:
+                hist.pop(0)
+            if use_smoothing:
+                nh = len(hist)
+                stable = hist[-1] if nh < 3 else sum(hist) / nh >= mp
+                raw["has_piece"] = stable
+                if should and raw_has == stable:
+                    refresh |= bit
+                    refreshed.append(pos)
+            elif should:
+                refresh |= bit
+                refreshed.append(pos)
+            results[pos] = raw
+        if refresh:
+            state.set_ref_mask(refresh)
+            refs._mark(refreshed)
+        return results, visual_changes
+
+    def _detect_all_pieces_views(self, squares_dict, use_smoothing=True, use_delta=True, squares_to_check=None):
+        """The same for squares that are NOT views of one image (or a subset of the known squares): packed view
+        copies and separate statistics / HoughCircles calls."""
         results, visual_changes, refresh = {}, set(), []
         if not squares_dict:
             return results, visual_changes

@@ -228,6 +228,88 @@ CBV_API int cbv_squares_get(cbv_squares* sq, int which, int index, void* out);
 CBV_API int cbv_squares_set(cbv_squares* sq, int which, int index, const void* in);
 CBV_API int cbv_squares_geometry(cbv_squares* sq, int index, int* w, int* h);
 
+/* ------------------------------------------------------------------ */
+/* one call per frame for the reference's own call pattern              */
+/* (game_session.py:124-161, calibrate_sensitivity.py:142-157):         */
+/* warp_image -> split_board -> detect_all_pieces / detect_changes      */
+/* ------------------------------------------------------------------ */
+/* The image all squares of a split_board() dict are views of (grid_extractor.py:46,153: img_warped[y:y+h, x:x+w]). */
+typedef struct {
+    const uint8_t* data;
+    int32_t w, h, stride, cn;
+} cbv_host_image;
+
+/* _preprocess / _preprocess_square of the n ROIs of ONE host image: the rows of the image the ROIs cover are uploaded
+ * with one copy at call time (no host pointer is kept, so pixels the caller drew on the board since warp_image are
+ * seen), then as cbv_squares_load_dev.  Replaces cbv_squares_load's 64 packed view copies for split_board's case. */
+CBV_API int cbv_squares_load_image(cbv_squares* sq, const cbv_host_image* img, const cbv_roi* rois, int n, int blur_k);
+/* reference_squares[pos] = gray.copy() (piece_detector.py:95-97) for the squares of a 64-bit set (bit i = square i);
+ * asynchronous: the set rides in the launch, nothing is read from host memory afterwards. */
+CBV_API int cbv_squares_set_ref_mask(cbv_squares* sq, uint64_t mask);
+
+#define CBV_METHOD_NONE 0
+#define CBV_METHOD_HOUGH 1        /* 'hough'       confidence 0.9  (piece_detector.py:310-317) */
+#define CBV_METHOD_TOWER_TOP 2    /* 'tower_top'   confidence 0.75 */
+#define CBV_METHOD_CENTER_DIFF 3  /* 'center_diff' confidence min(1, diff / 80) (piece_detector.py:324-331) */
+#define CBV_METHOD_SYMMETRY 4     /* 'symmetry'    confidence = score (piece_detector.py:337-343) */
+/* detect_piece's result dict (piece_detector.py:289-299) + detect_all_pieces' per-square gate (piece_detector.py:367-395) */
+typedef struct {
+    uint8_t has_piece;        /* raw result of detect_piece (before the temporal smoothing, which stays with the caller) */
+    uint8_t method;           /* CBV_METHOD_* */
+    uint8_t changed;          /* has_changed_visual: no reference yet, or mean |gray - reference| > change_threshold */
+    uint8_t should_process;   /* piece_detector.py:381-389 */
+    uint8_t evaluated;        /* should_process or not cached: the fields of detect_piece below are fresh */
+    uint8_t pad[3];
+    int32_t cx, cy, radius;   /* result['center'], result['radius'] when has_piece */
+    double confidence;
+    double center_border_diff;
+} cbv_piece_result;
+/* detect_piece for one square from its statistics and its HoughCircles record (NULL = HoughCircles not run); host
+ * only, no GPU.  CBV_ERR_UNSUPPORTED when the record carries CBV_HOUGH_OVERFLOW. */
+CBV_API int cbv_decide_piece(const cbv_sq_stats* st, const cbv_hough_result* hg, int w, int h, double circle_threshold,
+                             cbv_piece_result* out);
+
+typedef struct {
+    double change_threshold;   /* 25   piece_detector.py:50 */
+    double circle_threshold;   /* 0.6  piece_detector.py:36 */
+    cbv_hough_params hough;
+    uint64_t has_ref;          /* bit i: square i is in reference_squares */
+    uint64_t cached;           /* bit i: square i is in cached_results */
+    uint64_t check;            /* squares_to_check (piece_detector.py:348), bit i */
+    int32_t check_given;       /* squares_to_check is not None */
+    int32_t use_delta;
+} cbv_detect_params;
+/* The device half of PieceDetector.detect_all_pieces (piece_detector.py:348-440) on the n squares of one host image, in
+ * ONE call with one wait: upload, _preprocess_square, _has_changed against the device-resident references, the
+ * should_process gate, HoughCircles on exactly the squares the reference would run it on (evaluated squares whose std
+ * is >= 15), detect_piece's decision.  History, smoothing and the reference refresh (cbv_squares_set_ref_mask) stay
+ * with the caller, which owns detection_history / cached_results like the reference's class does. */
+CBV_API int cbv_squares_detect_all(cbv_squares* sq, const cbv_host_image* img, const cbv_roi* rois, int n,
+                                   const cbv_detect_params* prm, cbv_piece_result* out /* n */);
+
+typedef struct {
+    double z_threshold;        /* change_detector.py:23 */
+    uint64_t select;           /* squares to report on: focus_squares, or all, that are in `squares` and calibrated */
+    double circle_threshold;   /* of the detector's own PieceDetector (change_detector.py:33) */
+    cbv_hough_params hough;
+} cbv_change_params;
+typedef struct {
+    uint8_t in_result;         /* pct_changed >= 5: the square is in detect_changes_detailed's dict */
+    uint8_t intensity;         /* 1 LEVE, 2 PARCIAL, 3 TOTAL (change_detector.py:141-148) */
+    uint8_t is_circular;       /* piece_detector.detect_piece(square)['has_piece'] (change_detector.py:152-154) */
+    uint8_t pad;
+    float z_max;               /* np.max(z_score) */
+    uint32_t z_count, n;       /* pct_changed = z_count / n * 100 */
+} cbv_change_result;
+/* ChangeDetector.detect_changes_detailed (change_detector.py:105-167) on the n squares of one host image in one call:
+ * upload, _preprocess with the detector's blur, z-score statistics against the device-resident model, and for the
+ * squares that changed the circular test on the same pixels preprocessed the PieceDetector way (k = 5). */
+CBV_API int cbv_squares_detect_changes(cbv_squares* sq, const cbv_host_image* img, const cbv_roi* rois, int n, int blur_k,
+                                       const cbv_change_params* prm, cbv_change_result* out /* n */);
+/* tests: fill partially uploaded staging buffers (cbv_warp_perspective's frame, the squares' image rows) with 0xA5
+ * before the copy, so a read outside the uploaded part cannot go unnoticed */
+CBV_API int cbv_debug_poison(cbv_ctx* ctx, int on);
+
 /* cv2.Canny(img, threshold1, threshold2) with the default aperture 3 and L1 gradient, as
  * SmartGridExtractor.refine_grid (grid_extractor.py:66-121) uses it on the warped board at calibration time
  * (SURVEY §8 f3).  img: 1 or 3 channels (BGR is converted with BGR2GRAY first); edges: 0 / 255. */
@@ -358,6 +440,9 @@ CBV_API int cbv_pipeline_set_check_squares(cbv_pipeline* p, int slot0, int count
 CBV_API int cbv_pipeline_update_references(cbv_pipeline* p, int slot, int reset_noise);
 /* enqueue enhance -> warp -> detect for frames [slot0, slot0+count) in stream order; asynchronous */
 CBV_API int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count);
+/* CBV_ERR_UNSUPPORTED (with `out` filled) when a HoughCircles candidate list overflowed even the second pass in a run
+ * since the previous call: the counter is cleared on read, so later frames are not affected; cbv_pipeline_hough's flags
+ * name the squares. */
 CBV_API int cbv_pipeline_results(cbv_pipeline* p, int slot0, int count, cbv_frame_result* out);
 /* NoiseHandler outputs of the same frames (fed by their visual_changes, like game_session.py:165) */
 CBV_API int cbv_pipeline_noise_results(cbv_pipeline* p, int slot0, int count, cbv_noise_result* out);

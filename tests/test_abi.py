@@ -54,7 +54,9 @@ def test_header_is_plain_c_and_every_struct_has_the_ctypes_layout(tmp_path):
     pairs = [("cbv_color_profile", N.ColorProfile), ("cbv_enhance_params", N.EnhanceParams), ("cbv_roi", N.Roi),
              ("cbv_square_view", N.SquareView), ("cbv_sq_stats", N.SqStats), ("cbv_scene", N.Scene),
              ("cbv_hough_params", N.HoughParams), ("cbv_hough_result", N.HoughResult), ("cbv_pipeline_config", N.PipelineConfig),
-             ("cbv_frame_result", N.FrameResult), ("cbv_noise_result", N.NoiseResult), ("cbv_noise_state", N.NoiseDevState)]
+             ("cbv_frame_result", N.FrameResult), ("cbv_noise_result", N.NoiseResult), ("cbv_noise_state", N.NoiseDevState),
+             ("cbv_host_image", N.HostImage), ("cbv_piece_result", N.PieceResult), ("cbv_detect_params", N.DetectParams),
+             ("cbv_change_params", N.ChangeParams), ("cbv_change_result", N.ChangeResult)]
     lines = ['#include <stddef.h>', '#include <stdio.h>', '#include "cbv.h"', '#include "cbv_chess.h"', 'int main(void) {']
     for cname, cls in pairs:
         lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
