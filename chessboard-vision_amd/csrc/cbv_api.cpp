@@ -58,6 +58,13 @@ int ctx_hstage(cbv_ctx* ctx, size_t bytes, u8** p)
     return CBV_OK;
 }
 
+int ctx_worker_stream(cbv_ctx* ctx, hipStream_t* slot, hipStream_t* out)
+{
+    if (!*slot) CBV_HIP(ctx, hipStreamCreateWithFlags(slot, hipStreamNonBlocking));
+    *out = *slot;
+    return CBV_OK;
+}
+
 void dev_free(DevBuf* b)
 {
     if (b->p) (void)hipFree(b->p);
@@ -234,6 +241,10 @@ extern "C" void cbv_ctx_destroy(cbv_ctx* ctx)
     if (ctx->ptabs) (void)hipFree(ctx->ptabs);
     if (ctx->btabs) (void)hipFree(ctx->btabs);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    for (auto& st : ctx->lane_streams)
+        if (st) (void)hipStreamDestroy(st);
+    if (ctx->scan_stream) (void)hipStreamDestroy(ctx->scan_stream);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -1220,12 +1231,14 @@ extern "C" int cbv_squares_detect_all(cbv_squares* s, const cbv_host_image* img,
     u8* hst;
     const size_t o_back = 4096; // the descriptors are staged in front of it
     RC(ctx_hstage(ctx, 65536, &hst));
+    FastLayout L;
+    RC(fast_layout(s, &L));
+    // worklist and retry counters; in front of the upload, whose host-blocking copy would otherwise leave the GPU idle
+    // while this launch is submitted
+    CBV_HIP(ctx, hipMemsetAsync(s->d_fast.p, 0, 1024, ctx->stream));
     RC(squares_stage_host_image(s, img, rois, n, 5, hst));
     HoughCfg hc;
     RC(hough_cfg(ctx, &prm->hough, s->descs, &hc));
-    FastLayout L;
-    RC(fast_layout(s, &L));
-    CBV_HIP(ctx, hipMemsetAsync(s->d_fast.p, 0, 1024, ctx->stream)); // worklist and retry counters
     DetectMasks dm;
     dm.has_ref = s->has_ref ? prm->has_ref : 0;
     dm.cached = prm->cached;
@@ -1546,23 +1559,16 @@ extern "C" void cbv_pipeline_destroy(cbv_pipeline* p)
         dev_free(&p->lane_small[l]);
         dev_free(&p->lane_work[l]);
         if (p->lane_done[l]) (void)hipEventDestroy(p->lane_done[l]);
-        if (p->lane_stream[l]) (void)hipStreamDestroy(p->lane_stream[l]);
     }
     if (p->start_ev) (void)hipEventDestroy(p->start_ev);
-    if (p->scan_stream) {
-        (void)hipStreamSynchronize(p->scan_stream);
-        (void)hipStreamDestroy(p->scan_stream);
-    }
+    if (p->scan_stream) (void)hipStreamSynchronize(p->scan_stream); // (the worker streams belong to the context)
     for (auto& r : p->runs) {
         (void)hipEventDestroy(r.lanes_ev);
         (void)hipEventDestroy(r.scan_ev);
         dev_free(&r.retry);
     }
     if (p->main_done) (void)hipEventDestroy(p->main_done);
-    if (p->copy_stream) {
-        (void)hipStreamSynchronize(p->copy_stream);
-        (void)hipStreamDestroy(p->copy_stream);
-    }
+    if (p->copy_stream) (void)hipStreamSynchronize(p->copy_stream);
     for (auto& c : p->copies) (void)hipEventDestroy(c.ev);
     if (p->host_ring) (void)hipHostFree(p->host_ring);
     if (p->h_stage) (void)hipHostFree(p->h_stage);
@@ -1633,7 +1639,7 @@ extern "C" int cbv_pipeline_configure(cbv_pipeline* p, const cbv_pipeline_config
         SmallLayout SL;
         RC(small_layout(ctx, &p->lane_small[l], cfg->enhance.tiles_x * cfg->enhance.tiles_y, chunk, &SL, cfg->enhance.tiles_x, cfg->enhance.tiles_y));
         RC(dev_ensure(ctx, &p->lane_work[l], sizeof(u32) * (1 + (size_t)CBV_MAX_SQUARES * chunk)));
-        if (l > 0 && !p->lane_stream[l]) CBV_HIP(ctx, hipStreamCreateWithFlags(&p->lane_stream[l], hipStreamNonBlocking));
+        if (l > 0) RC(ctx_worker_stream(ctx, &ctx->lane_streams[l], &p->lane_stream[l]));
         if (!p->lane_done[l]) CBV_HIP(ctx, hipEventCreateWithFlags(&p->lane_done[l], hipEventDisableTiming));
     }
     CBV_HIP(ctx, hipMalloc((void**)&p->warped, p->warped_stride * p->max_frames));
@@ -1769,7 +1775,7 @@ extern "C" int cbv_pipeline_submit(cbv_pipeline* p, int slot0, int count)
     if (slot0 < 0 || count <= 0 || slot0 + count > p->max_frames) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_pipeline_submit: bad slot range");
     if (!p->host_ring) return cbv_fail(ctx, CBV_ERR_STATE, "cbv_pipeline_submit: cbv_pipeline_host_ring() was never called");
     CBV_ENTER(ctx);
-    if (!p->copy_stream) CBV_HIP(ctx, hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
+    if (!p->copy_stream) RC(ctx_worker_stream(ctx, &ctx->copy_stream, &p->copy_stream));
     // do not overwrite device slots a run that is still in flight reads: ANY such run, not only the last one
     retire_runs(p);
     {
@@ -1848,7 +1854,13 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
     // (the scans' state is sequential over runs).
     const bool inline_scan = count <= 2;
     const int chunks = (count + p->chunk - 1) / p->chunk;
-    const int lanes_used = std::min(p->n_lanes, chunks);
+    // Chunks go round the lanes, and the round continues from run to run and from pipeline to pipeline of this context
+    // (ctx->lane_rr): K camera streams whose runs are one chunk each would otherwise all pile on lane 0 and lose the
+    // overlap of the lanes.  Short (latency) runs start on the caller's stream.
+    const int lane_base = inline_scan ? 0 : ctx->lane_rr % p->n_lanes;
+    if (!inline_scan) ctx->lane_rr = (ctx->lane_rr + chunks) % (12 * 1024);
+    bool lane_used[cbv_pipeline::MAX_LANES] = {false, false, false, false};
+    for (int c = 0; c < chunks && c < p->n_lanes; c++) lane_used[(lane_base + c) % p->n_lanes] = true;
     if (inline_scan) {
         retire_runs(p);
         RC(join_scan(p));
@@ -1875,13 +1887,16 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
             CBV_HIP(ctx, hipStreamWaitEvent(main_stream, c.ev, 0));
             c.pending = false;
         }
-    if (lanes_used > 1) {
+    bool forked = false;
+    for (int l = 1; l < p->n_lanes; l++) forked = forked || lane_used[l];
+    if (forked) {
         CBV_HIP(ctx, hipEventRecord(p->start_ev, main_stream));
-        for (int l = 1; l < lanes_used; l++) CBV_HIP(ctx, hipStreamWaitEvent(p->lane_stream[l], p->start_ev, 0));
+        for (int l = 1; l < p->n_lanes; l++)
+            if (lane_used[l]) CBV_HIP(ctx, hipStreamWaitEvent(p->lane_stream[l], p->start_ev, 0));
     }
     int ci = 0, rc_all = CBV_OK;
     for (int s0 = slot0; s0 < slot0 + count && rc_all == CBV_OK; s0 += p->chunk, ci++) {
-        const int lane = ci % p->n_lanes;
+        const int lane = (lane_base + ci) % p->n_lanes;
         ctx->stream = lane == 0 ? main_stream : p->lane_stream[lane];
         SmallLayout SL;
         rc_all = small_layout(ctx, &p->lane_small[lane], cfg.enhance.tiles_x * cfg.enhance.tiles_y, p->chunk, &SL, cfg.enhance.tiles_x, cfg.enhance.tiles_y);
@@ -1920,12 +1935,13 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
     if (rc_all) {
         // a launch failed after lanes were forked: whatever they already enqueued on these slots and scratch buffers must
         // not outlive the call unordered (no RunRec goes live for a failed run)
-        for (int l = 1; l < lanes_used; l++) (void)hipStreamSynchronize(p->lane_stream[l]);
+        for (int l = 1; l < p->n_lanes; l++)
+            if (lane_used[l]) (void)hipStreamSynchronize(p->lane_stream[l]);
         (void)hipStreamSynchronize(main_stream);
         return rc_all;
     }
     if (!p->scan_stream) {
-        CBV_HIP(ctx, hipStreamCreateWithFlags(&p->scan_stream, hipStreamNonBlocking));
+        RC(ctx_worker_stream(ctx, &ctx->scan_stream, &p->scan_stream));
         CBV_HIP(ctx, hipEventCreateWithFlags(&p->main_done, hipEventDisableTiming));
     }
     hipStream_t scan_on = inline_scan ? main_stream : p->scan_stream;
@@ -1934,10 +1950,11 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
         CBV_HIP(ctx, hipStreamWaitEvent(scan_on, p->main_done, 0));
     }
     // every forked lane is joined, in the inline case too (chunk = 1 puts the second frame of a two-frame run on lane 1)
-    for (int l = 1; l < lanes_used; l++) {
-        CBV_HIP(ctx, hipEventRecord(p->lane_done[l], p->lane_stream[l]));
-        CBV_HIP(ctx, hipStreamWaitEvent(scan_on, p->lane_done[l], 0));
-    }
+    for (int l = 1; l < p->n_lanes; l++)
+        if (lane_used[l]) {
+            CBV_HIP(ctx, hipEventRecord(p->lane_done[l], p->lane_stream[l]));
+            CBV_HIP(ctx, hipStreamWaitEvent(scan_on, p->lane_done[l], 0));
+        }
     // every lane has read its frames: a later cbv_pipeline_submit may overwrite these slots after this event
     CBV_HIP(ctx, hipEventRecord(rec->lanes_ev, scan_on));
     ctx->stream = scan_on;

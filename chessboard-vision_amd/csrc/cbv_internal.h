@@ -124,7 +124,16 @@ struct cbv_ctx {
     u8* h_stage = nullptr;
     size_t h_stage_cap = 0;
     int debug_poison = 0; // tests: fill partially uploaded staging buffers with 0xA5 first (cbv_debug_poison)
+
+    // Worker streams of the pipelines created on this context (lanes 1.., temporal scan, ingest copies).  They belong to
+    // the context, not to a pipeline: a HIP process has four hardware queues by default and streams beyond them share
+    // a queue and serialise, so K camera streams on one GPU (K pipelines) must not bring K sets of streams.  All
+    // pipelines of a context enqueue from under its lock, in order, so sharing changes no dependency.
+    hipStream_t lane_streams[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t scan_stream = nullptr, copy_stream = nullptr;
+    int lane_rr = 0; // next lane of the round the pipelines' chunks are dealt on (cbv_pipeline_run)
 };
+int ctx_worker_stream(cbv_ctx* ctx, hipStream_t* slot, hipStream_t* out);
 int ctx_hstage(cbv_ctx* ctx, size_t bytes, u8** p);
 
 extern thread_local std::string g_cbv_err;

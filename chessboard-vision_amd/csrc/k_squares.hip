@@ -334,7 +334,9 @@ __global__ __launch_bounds__(256) void k_squares_stats(const SquareDesc* __restr
 // produces, so they are taken as the pixels leave the vertical pass (one launch and one read of the plane less)
 // NT lanes per square: 256 in batched launches (the chip is full of squares), 1024 when a launch holds only a frame or
 // two (64-128 squares on 256 CUs: then a square's three passes are latency, and four times the lanes cut it).
-template <int NT>
+// GATE: the class-API launch (one frame: |gray - reference| and detect_all_pieces' per-square gate); the batched pipeline
+// launches compile without it
+template <int NT, bool GATE>
 __global__ __launch_bounds__(NT) void k_squares_pre5_stats(const u8* __restrict__ src, size_t src_frame_stride,
                                                              const SquareDesc* __restrict__ descs, u8* __restrict__ gray,
                                                              size_t gray_frame_stride, const float* __restrict__ mean,
@@ -404,7 +406,7 @@ __global__ __launch_bounds__(NT) void k_squares_pre5_stats(const u8* __restrict_
     const float* mp = mean ? mean + d.plane_off : nullptr;
     const float* vp = mean ? var + d.plane_off : nullptr;
     // class API: sum |gray - reference| of squares that have one (piece_detector.py:82-93)
-    const u8* rp = (ref && ((dm.has_ref >> blockIdx.x) & 1ull)) ? ref + d.plane_off : nullptr;
+    const u8* rp = (GATE && ref && ((dm.has_ref >> blockIdx.x) & 1ull)) ? ref + d.plane_off : nullptr;
     SqAccum A;
     sq_accum_init(A);
     for (int y = ty; y < h; y += NT / 16) {
@@ -414,10 +416,10 @@ __global__ __launch_bounds__(NT) void k_squares_pre5_stats(const u8* __restrict_
             const int gv = (int)((a2 + (1u << 15)) >> 16);
             const int i = y * w + x;
             outp[i] = (u8)gv;
-            sq_accum_px(A, gv, m[i], rp != nullptr, rp ? (int)rp[i] : 0, mp != nullptr, mp ? mp[i] : 0.f, mp ? vp[i] : 1.f, z_thresh);
+            sq_accum_px(A, gv, m[i], GATE && rp != nullptr, (GATE && rp) ? (int)rp[i] : 0, mp != nullptr, mp ? mp[i] : 0.f, mp ? vp[i] : 1.f, z_thresh);
         }
     }
-    sq_accum_finish(A, acc, zm, nanf_, n, mp != nullptr, out, nsq, decisions, want_hough, hough_work, hough_out, dm);
+    sq_accum_finish(A, acc, zm, nanf_, n, mp != nullptr, out, nsq, decisions, want_hough, hough_work, hough_out, GATE ? dm : DetectMasks());
 }
 
 int launch_squares_pre5_stats(cbv_ctx* ctx, const u8* src, size_t src_frame_stride, const SquareDesc* descs, int n, u8* gray,
@@ -429,11 +431,14 @@ int launch_squares_pre5_stats(cbv_ctx* ctx, const u8* src, size_t src_frame_stri
     if (max_px <= 0 || max_px > CBV_MAX_SQUARE_DIM * CBV_MAX_SQUARE_DIM) max_px = CBV_MAX_SQUARE_DIM * CBV_MAX_SQUARE_DIM;
     const size_t lds = (size_t)((max_px + 15) & ~15) + 2 * (size_t)max_px;
     prof_begin(ctx, CBV_K_SQUARES);
-    if ((long long)n * batch <= 2 * ctx->num_cus)
-        hipLaunchKernelGGL(k_squares_pre5_stats<1024>, dim3(n, 1, batch), dim3(1024), lds, ctx->stream, src, src_frame_stride, descs, gray,
+    if (dm.dflags)
+        hipLaunchKernelGGL((k_squares_pre5_stats<1024, true>), dim3(n, 1, batch), dim3(1024), lds, ctx->stream, src, src_frame_stride, descs, gray,
+                           gray_frame_stride, mean, var, masks, z_thresh, out, n, decisions, want_hough, hough_work, hough_out, ref, dm);
+    else if ((long long)n * batch <= 2 * ctx->num_cus)
+        hipLaunchKernelGGL((k_squares_pre5_stats<1024, false>), dim3(n, 1, batch), dim3(1024), lds, ctx->stream, src, src_frame_stride, descs, gray,
                            gray_frame_stride, mean, var, masks, z_thresh, out, n, decisions, want_hough, hough_work, hough_out, ref, dm);
     else
-        hipLaunchKernelGGL(k_squares_pre5_stats<256>, dim3(n, 1, batch), dim3(256), lds, ctx->stream, src, src_frame_stride, descs, gray,
+        hipLaunchKernelGGL((k_squares_pre5_stats<256, false>), dim3(n, 1, batch), dim3(256), lds, ctx->stream, src, src_frame_stride, descs, gray,
                            gray_frame_stride, mean, var, masks, z_thresh, out, n, decisions, want_hough, hough_work, hough_out, ref, dm);
     prof_end(ctx, CBV_K_SQUARES);
     CBV_HIP(ctx, hipGetLastError());

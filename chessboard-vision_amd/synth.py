@@ -29,6 +29,10 @@ SCENES = {
                    white=(245, 245, 240), black=(20, 20, 25), noise=3, radius=0.42),
     "dim": dict(bg_lo=24, bg_span=8, light=(62, 66, 70), dark=(40, 43, 48),
                 white=(84, 84, 82), black=(21, 21, 22), noise=1, radius=0.42),
+    # every byte uniform over 0..255 (mid-gray everywhere + noise of amplitude 127 wraps nothing: 128 +- 127): the worst
+    # case for data-dependent gathers; there is no board to detect in it
+    "white_noise": dict(bg_lo=128, bg_span=1, light=(128, 128, 128), dark=(128, 128, 128),
+                        white=(128, 128, 128), black=(128, 128, 128), noise=127, radius=0.42),
 }
 
 
