@@ -18,7 +18,7 @@ LIB = os.path.join(LIBDIR, "libcbv_hip.so")
 SOURCES = ["cbv_api.cpp", "cbv_tables.cpp", "k_enhance.hip", "k_bilateral.hip", "k_warp.hip", "k_analysis.hip",
            "k_squares.hip", "k_hough.hip", "k_canny.hip", "chess_rules.cpp", "contours.cpp"]
 HEADERS = ["cbv_internal.h", "cbv_device.h", os.path.join("..", "..", "include", "cbv.h")]
-FLAGS = [*(["-DHG_TIMING"] if os.environ.get("HG_TIMING") else []), *(["-DSH_TIMING"] if os.environ.get("SH_TIMING") else []), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
+FLAGS = [*(["-DHG_TIMING"] if os.environ.get("HG_TIMING") else []), *(["-DBL_TWO_COPIES"] if os.environ.get("BL_TWO_COPIES") else []), *(["-DSH_TIMING"] if os.environ.get("SH_TIMING") else []), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-x", "hip"]
 
 

@@ -52,7 +52,13 @@ __global__ __launch_bounds__(NT) void k_bilateral(const u8* __restrict__ src, u8
                                                            SatGate gate)
 {
     // static LDS (69 KB): compile-time addresses let the table gather use the ds_read immediate offset
+#ifdef BL_TWO_COPIES
+    // experiment (profiles/r03/bilateral_two_copies.txt): a second copy of the table 16 banks further on, used by the odd
+    // strips, so that two lanes of a half-wave whose distances differ by a multiple of 32 no longer meet in one bank
+    __shared__ __attribute__((aligned(16))) float fw[2 * BL_LUT_WORDS + 16];
+#else
     __shared__ __attribute__((aligned(16))) float fw[BL_LUT_WORDS];              // [class][768] folded weights
+#endif
     constexpr int BL_TH = NT / 16, BL_THREADS = NT;
     __shared__ __attribute__((aligned(16))) u32 tile[(BL_TH + 2 * R) * BL_PITCH];
     constexpr int ROWS = BL_TH + 2 * R;
@@ -62,6 +68,10 @@ __global__ __launch_bounds__(NT) void k_bilateral(const u8* __restrict__ src, u8
 
     const int tid = threadIdx.x;
     for (int i = tid; i < bt->ncls * 768; i += BL_THREADS) fw[i] = (&bt->folded[0][0])[i];
+#ifdef BL_TWO_COPIES
+    for (int i = tid; i < bt->ncls * 768; i += BL_THREADS) fw[BL_LUT_WORDS + 16 + i] = (&bt->folded[0][0])[i];
+    const u32 copy_off = (tid & 1) ? (u32)(BL_LUT_WORDS + 16) : 0u;
+#endif
 
     const int tiles_per_frame = ts.cum[ts.n]; // the tiles of this launch's region (TileSet), not of the whole frame
     const int ntiles = tiles_per_frame * batch;
@@ -206,11 +216,16 @@ __global__ __launch_bounds__(NT) void k_bilateral(const u8* __restrict__ src, u8
                 for (int dx = -R; dx <= R; dx++) {
                     const int toff = off[a][dx + R];
                     if (toff < 0) continue; // scalar branch
+#ifdef BL_TWO_COPIES
+                    const u32 tacc = (u32)toff + copy_off; // one vector add per tap, shared by the four outputs of the row
+#else
+                    const u32 tacc = (u32)toff;
+#endif
 #pragma unroll
                     for (int o = 0; o < 4; o++) {
                         const int j = o + 4 + dx;
                         // word index class * 768 + |db| + |dg| + |dr| in one v_sad_u8 (the class offset is its accumulator)
-                        const u32 idx = __builtin_amdgcn_sad_u8(p[j], ctr[a][o], (u32)toff);
+                        const u32 idx = __builtin_amdgcn_sad_u8(p[j], ctr[a][o], tacc);
                         const float wgt = *(const float*)((const u8*)fw + (idx << 2));
                         // v_muladd(v_cvt_f32(b), w, sum_b): fused, like OpenCV's FMA3-dispatched body
                         sb[a][o] = __fmaf_rn(fb[j], wgt, sb[a][o]);
