@@ -134,64 +134,53 @@ __global__ __launch_bounds__(256) void k_color_lab_hist(const u8* __restrict__ s
         const int ey = ty * cg.th + rr;
         const int sy = d_reflect101(ey, g.h);
         const bool row_in = ey < g.h;
+        // one pixel: colour profile, BGR2LAB, histogram.  Straight-line code (no per-pixel predicate), so the four
+        // pixels of a group interleave and their table gathers overlap.
+        auto do_px = [&](int b, int gg, int r) -> u32 {
+            u32 v = (u32)b | ((u32)gg << 8) | ((u32)r << 16);
+            if (do_profile) {
+                v = d_profile_px(L, b, gg, r, radical);
+                b = v & 255;
+                gg = (v >> 8) & 255;
+                r = (v >> 16) & 255;
+            }
+            if (do_lab) {
+                int oL;
+                v = d_bgr2lab_px(L, b, gg, r, oL);
+                atomicAdd((u32*)((u8*)L.hist + __builtin_amdgcn_alignbit((u32)oL, hist_lane, 27)), 1u);
+            }
+            return v;
+        };
         for (int gi = lane; gi < groups; gi += 64) {
             const int ex = ex0 + gi * 4;
             const int npx = min(4, cg.tw - gi * 4);
-            Px4 px;
-            const bool fast = aligned && npx == 4 && ex + 3 < g.w;
-            if (fast) {
+            if (aligned && npx == 4 && ex + 3 < g.w) {
                 const u32* p = (const u32*)(sf + (size_t)sy * g.stride + (size_t)ex * 3);
-                px.d[0] = p[0];
-                px.d[1] = p[1];
-                px.d[2] = p[2];
-            } else {
-                px.d[0] = px.d[1] = px.d[2] = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    if (k < npx) {
-                        int sx = d_reflect101(ex + k, g.w);
-                        const u8* p = sf + (size_t)sy * g.stride + (size_t)sx * 3;
-                        px_set(px, 3 * k, p[0]);
-                        px_set(px, 3 * k + 1, p[1]);
-                        px_set(px, 3 * k + 2, p[2]);
-                    }
-                }
-            }
-            u32 P[4] = {0, 0, 0, 0}; // per pixel: three output bytes in the low 24 bits
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (k < npx) {
-                    int b = px_get(px, 3 * k), gg = px_get(px, 3 * k + 1), r = px_get(px, 3 * k + 2);
-                    u32 v = (u32)b | ((u32)gg << 8) | ((u32)r << 16);
-                    if (do_profile) {
-                        v = d_profile_px(L, b, gg, r, radical);
-                        b = v & 255;
-                        gg = (v >> 8) & 255;
-                        r = (v >> 16) & 255;
-                    }
-                    if (do_lab) {
-                        int oL;
-                        v = d_bgr2lab_px(L, b, gg, r, oL);
-                        atomicAdd((u32*)((u8*)L.hist + __builtin_amdgcn_alignbit((u32)oL, hist_lane, 27)), 1u);
-                    }
-                    P[k] = v;
-                }
-            }
-            if (row_in) {
-                if (fast) {
+                const u32 d0 = p[0], d1 = p[1], d2 = p[2];
+                // bytes: b0 g0 r0 b1 | g1 r1 b2 g2 | r2 b3 g3 r3
+                const u32 P0 = do_px(d0 & 255u, (d0 >> 8) & 255u, (d0 >> 16) & 255u);
+                const u32 P1 = do_px(d0 >> 24, d1 & 255u, (d1 >> 8) & 255u);
+                const u32 P2 = do_px((d1 >> 16) & 255u, d1 >> 24, d2 & 255u);
+                const u32 P3 = do_px((d2 >> 8) & 255u, (d2 >> 16) & 255u, d2 >> 24);
+                if (row_in) {
                     u32* q = (u32*)(df + (size_t)ey * g.stride + (size_t)ex * 3);
-                    q[0] = __builtin_amdgcn_perm(P[1], P[0], 0x04020100u);
-                    q[1] = __builtin_amdgcn_perm(P[2], P[1], 0x05040201u);
-                    q[2] = __builtin_amdgcn_perm(P[3], P[2], 0x06050402u);
-                } else {
+                    q[0] = __builtin_amdgcn_perm(P1, P0, 0x04020100u);
+                    q[1] = __builtin_amdgcn_perm(P2, P1, 0x05040201u);
+                    q[2] = __builtin_amdgcn_perm(P3, P2, 0x06050402u);
+                }
+                continue;
+            }
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        if (k < npx && ex + k < g.w) {
-                            u8* q = df + (size_t)ey * g.stride + (size_t)(ex + k) * 3;
-                            q[0] = (u8)(P[k] & 255);
-                            q[1] = (u8)((P[k] >> 8) & 255);
-                            q[2] = (u8)((P[k] >> 16) & 255);
-                        }
+            for (int k = 0; k < 4; k++) { // tile / row ends, unaligned rows: pixel by pixel (REFLECT_101 past the image)
+                if (k < npx) {
+                    const int sx = d_reflect101(ex + k, g.w);
+                    const u8* p = sf + (size_t)sy * g.stride + (size_t)sx * 3;
+                    const u32 P = do_px(p[0], p[1], p[2]);
+                    if (row_in && ex + k < g.w) {
+                        u8* q = df + (size_t)ey * g.stride + (size_t)(ex + k) * 3;
+                        q[0] = (u8)(P & 255);
+                        q[1] = (u8)((P >> 8) & 255);
+                        q[2] = (u8)((P >> 16) & 255);
                     }
                 }
             }
@@ -313,6 +302,9 @@ __device__ __forceinline__ int d_ab_to_xz(int i)
 
 #define CLAHE_MAX_TILES_X 32
 // RG = false: the whole-frame launch, with the region code compiled out
+// Register budget: 48 VGPRs.  Three of its waves then fit beside the three 120-register waves a 768-lane bilateral
+// workgroup keeps on every SIMD (the other lane of the pipeline runs the bilateral most of the time); a build that kept all
+// four pixels of a group in flight took 60, only two waves fitted, and the path lost 1 % although the kernel alone was faster.
 template <bool RG>
 __global__ __launch_bounds__(256) void k_clahe_apply(const u8* __restrict__ lab, const u32* __restrict__ packed,
                                                       u8* __restrict__ dst, Geom g, ClaheGeom cg,
@@ -323,9 +315,8 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const u8* __restrict__ lab,
     // that complement pass nothing for frames whose region already holds 0 and 255 (cbv_internal.h)
     if (RG && sat_gate_closed(gate, blockIdx.z)) return;
     // static LDS: table addresses become ds_read immediates (no per-lookup base add)
-    __shared__ u16 inv_gamma[INV_GAMMA_TAB_SIZE];
+    __shared__ u8 inv_gamma[INV_GAMMA_TAB_SIZE]; // sRGBInvGammaTab_b as bytes (every entry is <= 255): the index IS the address
     __shared__ u32 lab_yf[256];          // y | ify << 16: one gather for the pair
-    __shared__ int invc[16];
     extern __shared__ __align__(16) u32 pk[]; // [tiles_x + 1][256]: this band's packed corner words (k_clahe_lut)
 
     // band b holds the rows whose unclamped ty1 is b - 1
@@ -349,9 +340,12 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const u8* __restrict__ lab,
     if (RG && !invert && (y1 <= cov.y0 || y0 >= cov.y1)) return; // none of this workgroup's rows is in the region
     const int gx0 = cov.x0 >> 2, gx1 = (cov.x1 + 3) >> 2;
 
-    lds_copy(inv_gamma, st->inv_gamma, INV_GAMMA_TAB_SIZE * 2);
+    for (int i = threadIdx.x; i < INV_GAMMA_TAB_SIZE; i += blockDim.x) inv_gamma[i] = (u8)st->inv_gamma[i];
     lds_copy(lab_yf, st->lab_yf, 1024); // u16 pairs (y, ify) read back as one word
-    if (threadIdx.x < 9) invc[threadIdx.x] = st->inv[threadIdx.x];
+    // Lab2RGBinteger's nine coefficients: uniform loads, they stay in scalar registers
+    int invc[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) invc[i] = st->inv[i];
     const int pairs = cg.tiles_x + 1;
     lds_copy(pk, packed + ((size_t)blockIdx.z * (cg.tiles_y + 1) + band) * pairs * 256, pairs * 1024);
     __syncthreads();
@@ -364,78 +358,101 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const u8* __restrict__ lab,
     const int shift = LAB_SHIFT + (LAB_BASE_SHIFT - INV_GAMMA_SHIFT);
 
     // x interpolation parameters of a 4-pixel column group (tile pair, xa)
-    auto xparam = [&](int gi, int (&op)[4], float (&xa)[4], float (&xa1)[4]) {
+    auto xparam = [&](int gi, int (&op)[4], float (&xa)[4]) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const float txf = (float)(gi * 4 + k) * inv_tw - 0.5f;
             int tx1 = d_floor_f(txf);
             xa[k] = txf - (float)tx1;
-            xa1[k] = 1.0f - xa[k];
             op[k] = min(max(tx1 + 1, 0), cg.tiles_x) * 1024; // byte offset of the pixel's column pair in pk
         }
     };
+    // A pixel in three steps, so that the four pixels of a group run through each step together (straight-line code, no
+    // per-pixel predicate: their gathers overlap).
+    // 1: CLAHE's bilinear interpolation between the four corner LUTs on L, then the arguments of Lab2RGBinteger's two
+    //    ab -> xz conversions
+    auto px_front = [&](int v, int aa, int bb, int opk, float xak, float ya, float ya1, int& yv, int& ix, int& iz) {
+        const float xa1k = 1.0f - xak; // (recomputed per pixel: one instruction against a register held across the rows)
+        const u32 cw = *(const u32*)((const u8*)pk + opk + v * 4); // the four corner LUT values of L = v
+        float ra = (float)(cw & 255u) * xa1k + (float)((cw >> 8) & 255u) * xak;
+        float rb = (float)((cw >> 16) & 255u) * xa1k + (float)(cw >> 24) * xak;
+        float res = ra * ya1 + rb * ya;
+        const int LL = (int)__builtin_amdgcn_cvt_pk_u8_f32(res, 0, 0u); // round-half-even + saturate
+        const u32 yf = lab_yf[LL];
+        yv = (int)(yf & 0xFFFFu);
+        const int ify = (int)(yf >> 16);
+        const int adiv = ((5 * aa * 53687 + (1 << 7)) >> 13) - 128 * LAB_BASE / 500;
+        const int bdiv = ((bb * 41943 + (1 << 4)) >> 9) - 128 * LAB_BASE / 200 + 1;
+        ix = ify + adiv;
+        iz = ify - bdiv;
+    };
+    // 2: d_ab_to_xz.  Its cubic branch (i > 3390, i.e. f(t) above 6/29: every pixel that is not nearly black in that
+    //    coordinate) is evaluated for all lanes; the linear branch costs more instructions than the cubic one and is
+    //    entered by the WAVE only when some lane needs it (px_fix_low behind a ballot).
+    auto cubic = [](int i) { return (int)(((u32)__mul24((int)((u32)__mul24(i, i) >> LAB_BASE_SHIFT), i)) >> LAB_BASE_SHIFT); };
+    auto px_fix_low = [](int i, int& v) {
+        if (i <= 3390) v = i * 108 / 841 - LAB_BASE * 16 / 116 * 108 / 841;
+    };
+    // 3: the inverse matrix, the inverse gamma table, packing
+    auto px_back = [&](int xv, int yv, int zv) -> u32 {
+        // |x|,|y|,|z| < 2^17 and |coefficient| < 2^14: 24-bit multiplies are exact
+        int ro = D_DESCALE(__mul24(invc[0], xv) + __mul24(invc[1], yv) + __mul24(invc[2], zv), shift);
+        int go = D_DESCALE(__mul24(invc[3], xv) + __mul24(invc[4], yv) + __mul24(invc[5], zv), shift);
+        int bo = D_DESCALE(__mul24(invc[6], xv) + __mul24(invc[7], yv) + __mul24(invc[8], zv), shift);
+        ro = min(max(ro, 0), INV_GAMMA_TAB_SIZE - 1);
+        go = min(max(go, 0), INV_GAMMA_TAB_SIZE - 1);
+        bo = min(max(bo, 0), INV_GAMMA_TAB_SIZE - 1);
+        return d_pack3(inv_gamma[bo], inv_gamma[go], inv_gamma[ro]);
+    };
+    auto do_px = [&](int v, int aa, int bb, int opk, float xak, float ya, float ya1) -> u32 {
+        int yv, ix, iz;
+        px_front(v, aa, bb, opk, xak, ya, ya1, yv, ix, iz);
+        return px_back(d_ab_to_xz(ix), yv, d_ab_to_xz(iz));
+    };
     // one group of one row
-    auto do_row = [&](int gi, int y, const int (&op)[4], const float (&xa)[4], const float (&xa1)[4]) {
+    auto do_row = [&](int gi, int y, const int (&op)[4], const float (&xa)[4]) {
         const int x0 = gi * 4;
         const int npx = min(4, g.w - x0);
-        const bool fast = aligned && npx == 4;
         const float tyf = (float)y * inv_th - 0.5f;
         const float ya = tyf - (float)d_floor_f(tyf), ya1 = 1.0f - ya;
-        Px4 px;
-        u32 P[4] = {0, 0, 0, 0};
         const u8* p = sf + (size_t)y * g.stride + (size_t)x0 * 3;
-        if (fast) {
-            const u32* pw = (const u32*)p;
-            px.d[0] = pw[0];
-            px.d[1] = pw[1];
-            px.d[2] = pw[2];
-        } else {
-            px.d[0] = px.d[1] = px.d[2] = 0;
-#pragma unroll
-            for (int k = 0; k < 12; k++)
-                if (k < npx * 3) px_set(px, k, p[k]);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (k < npx) {
-                const int v = px_get(px, 3 * k);
-                const u32 cw = *(const u32*)((const u8*)pk + op[k] + v * 4); // the four corner LUT values of L = v
-                float ra = (float)(cw & 255u) * xa1[k] + (float)((cw >> 8) & 255u) * xa[k];
-                float rb = (float)((cw >> 16) & 255u) * xa1[k] + (float)(cw >> 24) * xa[k];
-                float res = ra * ya1 + rb * ya;
-                const int LL = (int)__builtin_amdgcn_cvt_pk_u8_f32(res, 0, 0u); // round-half-even + saturate
-                // Lab2RGBinteger
-                const int aa = px_get(px, 3 * k + 1), bb = px_get(px, 3 * k + 2);
-                const u32 yf = lab_yf[LL];
-                const int yv = (int)(yf & 0xFFFFu), ify = (int)(yf >> 16);
-                const int adiv = ((5 * aa * 53687 + (1 << 7)) >> 13) - 128 * LAB_BASE / 500;
-                const int bdiv = ((bb * 41943 + (1 << 4)) >> 9) - 128 * LAB_BASE / 200 + 1;
-                const int xv = d_ab_to_xz(ify + adiv), zv = d_ab_to_xz(ify - bdiv);
-                // |x|,|y|,|z| < 2^17 and |coefficient| < 2^14: 24-bit multiplies are exact
-                int ro = D_DESCALE(__mul24(invc[0], xv) + __mul24(invc[1], yv) + __mul24(invc[2], zv), shift);
-                int go = D_DESCALE(__mul24(invc[3], xv) + __mul24(invc[4], yv) + __mul24(invc[5], zv), shift);
-                int bo = D_DESCALE(__mul24(invc[6], xv) + __mul24(invc[7], yv) + __mul24(invc[8], zv), shift);
-                ro = min(max(ro, 0), INV_GAMMA_TAB_SIZE - 1);
-                go = min(max(go, 0), INV_GAMMA_TAB_SIZE - 1);
-                bo = min(max(bo, 0), INV_GAMMA_TAB_SIZE - 1);
-                // table entries are <= 255 by construction: saturate_cast is the identity
-                P[k] = d_pack3(inv_gamma[bo], inv_gamma[go], inv_gamma[ro]);
-            }
-        }
         u8* q = df + (size_t)y * g.stride + (size_t)x0 * 3;
-        if (fast) {
-            u32* qw = (u32*)q;
-            qw[0] = __builtin_amdgcn_perm(P[1], P[0], 0x04020100u);
-            qw[1] = __builtin_amdgcn_perm(P[2], P[1], 0x05040201u);
-            qw[2] = __builtin_amdgcn_perm(P[3], P[2], 0x06050402u);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (k < npx) {
-                    q[3 * k] = (u8)(P[k] & 255);
-                    q[3 * k + 1] = (u8)((P[k] >> 8) & 255);
-                    q[3 * k + 2] = (u8)((P[k] >> 16) & 255);
+        if (aligned && npx == 4) {
+            const u32* pw = (const u32*)p;
+            const u32 d0 = pw[0], d1 = pw[1], d2 = pw[2];
+            // bytes: L0 a0 b0 L1 | a1 b1 L2 a2 | b2 L3 a3 b3
+            // two pixels at a time: enough independent work to overlap the gathers, few enough live values for 48 VGPRs
+            auto pair = [&](int v0, int a0, int b0, int v1, int a1, int b1, int k0, u32& Pa, u32& Pb) {
+                int yv0, ix0, iz0, yv1, ix1, iz1;
+                px_front(v0, a0, b0, op[k0], xa[k0], ya, ya1, yv0, ix0, iz0);
+                px_front(v1, a1, b1, op[k0 + 1], xa[k0 + 1], ya, ya1, yv1, ix1, iz1);
+                int xv0 = cubic(ix0), zv0 = cubic(iz0), xv1 = cubic(ix1), zv1 = cubic(iz1);
+                if (__builtin_amdgcn_ballot_w64(min(min(ix0, iz0), min(ix1, iz1)) <= 3390)) { // wave-uniform: some lane is on the linear branch
+                    px_fix_low(ix0, xv0);
+                    px_fix_low(iz0, zv0);
+                    px_fix_low(ix1, xv1);
+                    px_fix_low(iz1, zv1);
                 }
+                Pa = px_back(xv0, yv0, zv0);
+                Pb = px_back(xv1, yv1, zv1);
+            };
+            u32 P0, P1, P2, P3;
+            pair(d0 & 255u, (d0 >> 8) & 255u, (d0 >> 16) & 255u, d0 >> 24, d1 & 255u, (d1 >> 8) & 255u, 0, P0, P1);
+            pair((d1 >> 16) & 255u, d1 >> 24, d2 & 255u, (d2 >> 8) & 255u, (d2 >> 16) & 255u, d2 >> 24, 2, P2, P3);
+            u32* qw = (u32*)q;
+            qw[0] = __builtin_amdgcn_perm(P1, P0, 0x04020100u);
+            qw[1] = __builtin_amdgcn_perm(P2, P1, 0x05040201u);
+            qw[2] = __builtin_amdgcn_perm(P3, P2, 0x06050402u);
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) { // ragged row end or unaligned rows: pixel by pixel
+            if (k < npx) {
+                const u32 P = do_px(p[3 * k], p[3 * k + 1], p[3 * k + 2], op[k], xa[k], ya, ya1);
+                q[3 * k] = (u8)(P & 255);
+                q[3 * k + 1] = (u8)((P >> 8) & 255);
+                q[3 * k + 2] = (u8)((P >> 16) & 255);
+            }
         }
     };
     if (RG && !invert && (gx0 > 0 || gx1 < groups)) {
@@ -446,9 +463,9 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const u8* __restrict__ lab,
         for (int item = threadIdx.x; item < ngr * nr; item += blockDim.x) {
             const int ry = item / ngr, gi = c0 + (item - ry * ngr);
             int op[4];
-            float xa[4], xa1[4];
-            xparam(gi, op, xa, xa1);
-            do_row(gi, r0 + ry, op, xa, xa1);
+            float xa[4];
+            xparam(gi, op, xa);
+            do_row(gi, r0 + ry, op, xa);
         }
         return;
     }
@@ -458,12 +475,12 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const u8* __restrict__ lab,
         const bool col_in = gi >= gx0 && gi < gx1;
         if (RG && !invert && !col_in) continue;
         int op[4];
-        float xa[4], xa1[4];
-        xparam(gi, op, xa, xa1);
+        float xa[4];
+        xparam(gi, op, xa);
         for (int y = y0; y < y1; y++) {
             const bool row_in = y >= cov.y0 && y < cov.y1;
             if (RG && (invert ? (row_in && col_in) : !row_in)) continue;
-            do_row(gi, y, op, xa, xa1);
+            do_row(gi, y, op, xa);
         }
     }
 }
