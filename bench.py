@@ -673,11 +673,11 @@ def main():
                     traffic_src = "profiles/pmc_traffic.json (committed rocprofv3 --pmc passes of this round; not measured in this run)"
             except Exception:
                 traffic = None
-        # vector lane-ops per pixel of the kernel: SQ_INSTS_VALU of the committed counter pass (profiles/r02), else the
+        # vector lane-ops per pixel of the kernel: SQ_INSTS_VALU of the committed counter pass (profiles/r03, else r02), else the
         # static count of the ISA (49 taps x 6 ops + 36 conversions per 8 px ... ~ 378)
         valu_ops_px, valu_src = 378.0, "static count of the ISA"
-        cf = os.path.join(ROOT, "profiles", "r02", "bilateral_counters.json")
-        if os.path.exists(cf):
+        cf = next((c for c in (os.path.join(ROOT, "profiles", r, "bilateral_counters.json") for r in ("r03", "r02")) if os.path.exists(c)), "")
+        if cf:
             try:
                 c = json.load(open(cf))
                 valu_ops_px, valu_src = float(c["valu_lane_ops_per_px"]), "SQ_INSTS_VALU, " + c["source"]
