@@ -981,13 +981,20 @@ extern "C" int cbv_squares_stats(cbv_squares* s, int use_ref, int use_model, dou
     return CBV_OK;
 }
 
-static int hough_cfg(cbv_ctx* ctx, const cbv_hough_params* prm, const std::vector<SquareDesc>& descs, HoughCfg* hc)
+// the checks of hough_cfg that need no square geometry (entry points run them before they change any state)
+static int hough_params_check(cbv_ctx* ctx, const cbv_hough_params* prm)
 {
     if (!prm || !(prm->dp > 0) || prm->param1 < 0 || prm->param2 < 0 || !(prm->max_radius_ratio >= 0) || !(prm->min_radius_ratio >= 0))
         return cbv_fail(ctx, CBV_ERR_ARG, "HoughCircles parameters are invalid");
     if (prm->max_radius_ratio > 4.0 || prm->min_radius_ratio > 4.0)
         return cbv_fail(ctx, CBV_ERR_ARG, "HoughCircles radius ratios above 4 squares are not supported (got %g, %g)", prm->min_radius_ratio,
                         prm->max_radius_ratio);
+    return CBV_OK;
+}
+
+static int hough_cfg(cbv_ctx* ctx, const cbv_hough_params* prm, const std::vector<SquareDesc>& descs, HoughCfg* hc)
+{
+    RC(hough_params_check(ctx, prm));
     memset(hc, 0, sizeof(*hc));
     hc->dp = (float)prm->dp < 1.f ? 1.f : (float)prm->dp;
     hc->canny_thr = (int)nearbyint(prm->param1);
@@ -1228,6 +1235,7 @@ extern "C" int cbv_squares_detect_all(cbv_squares* s, const cbv_host_image* img,
     cbv_ctx* ctx = s->ctx;
     if (!prm || !out) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_squares_detect_all: null argument");
     CBV_ENTER(ctx);
+    RC(hough_params_check(ctx, &prm->hough)); // before anything of the set changes
     u8* hst;
     const size_t o_back = 4096; // the descriptors are staged in front of it
     RC(ctx_hstage(ctx, 65536, &hst));
@@ -1282,6 +1290,7 @@ extern "C" int cbv_squares_detect_changes(cbv_squares* s, const cbv_host_image* 
     if (!prm || !out) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_squares_detect_changes: null argument");
     if (!s->has_model) return cbv_fail(ctx, CBV_ERR_STATE, "cbv_squares_detect_changes: not calibrated");
     CBV_ENTER(ctx);
+    RC(hough_params_check(ctx, &prm->hough));
     u8* hst;
     const size_t o_back = 4096, o_wk = 40960;
     RC(ctx_hstage(ctx, 65536, &hst));

@@ -216,3 +216,106 @@ def test_warp_image_uploads_only_what_it_samples(gpu_ctx, oracle, poison):
             M = get_perspective_transform(q, np.float32([[0, 0], [200, 0], [0, 150], [200, 150]]))
             assert np.array_equal(warp_perspective(fr, M, (200, 150), rot180=bool(k & 1)),
                                   oracle.rotate180(oracle.warp_perspective(fr, M, (200, 150))) if k & 1 else oracle.warp_perspective(fr, M, (200, 150)))
+
+
+def test_one_call_entry_points_fail_loudly(gpu_ctx):
+    """Argument and state errors of the one-call entry points come back as CBV_ERR_* with a message; a rejected call
+    leaves the set usable."""
+    import ctypes as C
+    from chessboard_vision_amd import _native as N
+    from chessboard_vision_amd._squares import SquareSet, plan_of
+    from chessboard_vision_amd.grid_extractor import GridExtractor
+    board = np.random.default_rng(1).integers(0, 255, (160, 160, 3), dtype=np.uint8)
+    sq = GridExtractor().split_board(board)
+    img, lay = plan_of(sq)
+    ss = SquareSet(gpu_ctx)
+    prm = N.DetectParams()
+    prm.change_threshold, prm.circle_threshold, prm.use_delta = 25.0, 0.6, 1
+    prm.hough = N.HoughParams(1.2, 100.0, 25.0, 0.2, 0.55)
+    out = np.zeros(64, N.record_dtype(N.PieceResult))
+    lib = gpu_ctx.lib
+    bad = (N.Roi * 64)()
+    for i in range(64):
+        bad[i].x0, bad[i].y0, bad[i].w, bad[i].h = lay.rects[i]
+    bad[63].x0 = 150  # 150 + 20 > 160
+    assert lib.cbv_squares_detect_all(ss.h, img, bad, 64, prm, out.ctypes.data) == -1
+    assert b"outside" in lib.cbv_last_error(gpu_ctx.h)
+    assert lib.cbv_squares_detect_all(ss.h, img, lay.rois, 0, prm, out.ctypes.data) == -1
+    assert lib.cbv_squares_detect_all(ss.h, img, lay.rois, 64, None, out.ctypes.data) == -1
+    prm.hough.max_radius_ratio = 9.0
+    assert lib.cbv_squares_detect_all(ss.h, img, lay.rois, 64, prm, out.ctypes.data) == -1
+    prm.hough.max_radius_ratio = 0.55
+    cp = N.ChangeParams()
+    cp.z_threshold, cp.select, cp.circle_threshold, cp.hough = 2.5, lay.all_mask, 0.6, prm.hough
+    cout = np.zeros(64, N.record_dtype(N.ChangeResult))
+    assert lib.cbv_squares_detect_changes(ss.h, img, lay.rois, 64, 5, cp, cout.ctypes.data) == -4  # not calibrated
+    assert lib.cbv_squares_set_ref_mask(ss.h, 1) == -4                                              # nothing loaded yet
+    # and after the refusals the set works
+    rows = ss.detect_all(img, lay, prm)
+    assert len(rows) == 64 and all(r[2] == 1 and r[4] == 1 for r in rows)  # no references yet: every square changed, evaluated
+    gray_img = N.HostImage()
+    gray_img.data, gray_img.w, gray_img.h, gray_img.stride, gray_img.cn = img.data, 160, 160, 480, 2
+    assert lib.cbv_squares_detect_all(ss.h, gray_img, lay.rois, 64, prm, out.ctypes.data) == -1   # 2 channels
+
+
+def test_grid_change_mid_stream_drops_the_references(gpu_ctx, oracle):
+    """Switching the grid (other square shapes) under a live detector voids the device planes: every square reads as
+    changed and is evaluated afresh, like a detector without references; going back does not revive old planes."""
+    from chessboard_vision_amd.board_detection import warp_image
+    from chessboard_vision_amd.piece_detector import PieceDetector
+    from ref_logic import RefPieceDetector
+    pts = S.scaled_corners(W, H)
+    lin, smart = _grid("linear"), _grid("smart")
+    det = PieceDetector()
+    f = oracle_frame(W, H, "normal", frame_idx=0)
+    warped = warp_image(f, pts)[0]
+    det.update_references(lin.split_board(warped))
+    r, v = det.detect_all_pieces(lin.split_board(warped))
+    assert v == set()
+    r, v = det.detect_all_pieces(smart.split_board(warped))  # 77..80-px squares instead of 77 x 77
+    assert len(v) == 64 and len(det.reference_squares) == 64  # all changed (no references), all refreshed afterwards
+    ref = RefPieceDetector(hough={})
+    want, _ = ref.detect_all_pieces(smart.split_board(warped))
+    assert {p: x["method"] for p, x in det.cached_results.items()} == {p: x["method"] for p, x in want.items()}
+    r, v = det.detect_all_pieces(smart.split_board(warped))
+    assert v == set()
+    r, v = det.detect_all_pieces(lin.split_board(warped))
+    assert len(v) == 64
+
+
+def test_detectors_on_one_context_from_two_threads(gpu_ctx, oracle):
+    """Two detectors driven from two threads on the one process-wide context (ctypes drops the GIL): the one-call entry
+    points hold the context's lock for their whole call and share its pinned staging safely."""
+    import threading
+    from chessboard_vision_amd.board_detection import warp_image
+    from chessboard_vision_amd.change_detector import ChangeDetector
+    from chessboard_vision_amd.piece_detector import PieceDetector
+    from ref_logic import RefChangeDetector, RefPieceDetector
+    pts = S.scaled_corners(W, H)
+    ge = _grid("smart")
+    boards = [warp_image(oracle_frame(W, H, "normal", frame_idx=t, frames_per_ply=2), pts)[0] for t in range(8)]
+    rp, rc = RefPieceDetector(hough={}), RefChangeDetector(hough={})
+    rc.calibrate(ge.split_board(boards[0]))
+    want_p = [rp.detect_all_pieces(ge.split_board(b)) for b in boards]
+    want_c = [rc.detect_changes_detailed(ge.split_board(b)) for b in boards]
+    errs = []
+
+    def pieces():
+        d = PieceDetector()
+        for b, w_ in zip(boards, want_p):
+            if d.detect_all_pieces(ge.split_board(b)) != w_:
+                errs.append("pieces")
+
+    def changes():
+        d = ChangeDetector()
+        d.calibrate(ge.split_board(boards[0]))
+        for b, w_ in zip(boards, want_c):
+            if d.detect_changes_detailed(ge.split_board(b)) != w_:
+                errs.append("changes")
+
+    ts = [threading.Thread(target=f) for f in (pieces, changes, pieces)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
