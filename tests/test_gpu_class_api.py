@@ -319,3 +319,19 @@ def test_detectors_on_one_context_from_two_threads(gpu_ctx, oracle):
     for t in ts:
         t.join()
     assert not errs, errs
+
+
+def test_session_loop_example_recognises_the_scripted_game(gpu_ctx):
+    """examples/session_on_frame.py: GameSession.on_frame's calls on the drop-in classes (enhancer, warp_image, smart
+    grid, smart-scan sets from the rules engine, detect_all_pieces, NoiseHandler, the stability rule) over the whole
+    scripted game at 1080p: all 16 plies are recognised and the FEN is the closed Ruy Lopez."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "session_on_frame.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("frame")]
+    assert [l.split()[2] for l in lines] == ["e2e4", "e7e5", "g1f3", "b8c6", "f1b5", "a7a6", "b5a4", "g8f6", "e1g1", "f8e7", "f1e1",
+                                             "b7b5", "a4b3", "d7d6", "c2c3", "e8g8"]
+    assert "final FEN r1bq1rk1/2p1bppp/p1np1n2/1p2p3/4P3/1BP2N2/PP1P1PPP/RNBQR1K1 w - - 1 9" in r.stdout
