@@ -35,12 +35,19 @@ int launch_reset_aux(cbv_ctx* ctx, u32* aux, int tiles, int batch)
 // ---------------------------------------------------------------------------
 // colour profile + BGR2LAB + tile histograms
 // ---------------------------------------------------------------------------
+// acc + c * x with a 24-bit multiply, c uniform (a scalar register): one v_mad_i32_i24, kept as one by the inline assembly
+__device__ __forceinline__ int d_mad24s(int c, int x, int acc)
+{
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "s"(c), "v"(x), "v"(acc));
+    return r;
+}
+
 struct ColorLds {
     int sdiv[256];
     int hdiv[256];
     u16 cbrt[LAB_CBRT_TAB_SIZE_B];
     u16 gamma[256];
-    int fwd[9];
     ProfileTabs pt;
     u32 hist[256 * 8]; // 8 bank-interleaved copies: hist[bin * 8 + (lane & 7)]
 };
@@ -82,7 +89,8 @@ __device__ __forceinline__ u32 d_profile_px(const ColorLds& L, int b, int g, int
 }
 
 // RGB2Lab_b (integer).  Returns L | a << 8 | b << 16; oL receives L.
-__device__ __forceinline__ u32 d_bgr2lab_px(const ColorLds& L, int b, int g, int r, int& oL)
+// fw: RGB2Lab_b's nine coefficients, uniform (scalar registers)
+__device__ __forceinline__ u32 d_bgr2lab_px(const ColorLds& L, const int (&fw)[9], int b, int g, int r, int& oL)
 {
     const int Lscale = (116 * 255 + 50) / 100;
     const int Lshift = -((16 * 255 * (1 << LAB_SHIFT2) + 50) / 100);
@@ -90,9 +98,12 @@ __device__ __forceinline__ u32 d_bgr2lab_px(const ColorLds& L, int b, int g, int
     // data-dependent addresses): three 16-bit gamma reads + nine 24-bit multiplies beat three
     // 16-byte reads of premultiplied rows.
     const int R = L.gamma[b], G = L.gamma[g], B = L.gamma[r]; // positional naming as in OpenCV
-    const int fX = L.cbrt[(__mul24(R, L.fwd[0]) + __mul24(G, L.fwd[1]) + __mul24(B, L.fwd[2]) + (1 << (LAB_SHIFT - 1))) >> LAB_SHIFT];
-    const int fY = L.cbrt[(__mul24(R, L.fwd[3]) + __mul24(G, L.fwd[4]) + __mul24(B, L.fwd[5]) + (1 << (LAB_SHIFT - 1))) >> LAB_SHIFT];
-    const int fZ = L.cbrt[(__mul24(R, L.fwd[6]) + __mul24(G, L.fwd[7]) + __mul24(B, L.fwd[8]) + (1 << (LAB_SHIFT - 1))) >> LAB_SHIFT];
+    // (each row a chain of three multiply-adds from the rounding constant: 3 instructions, where hipcc left to itself
+    // forms two products and a three-way add)
+    const int half = 1 << (LAB_SHIFT - 1);
+    const int fX = L.cbrt[d_mad24s(fw[2], B, d_mad24s(fw[1], G, d_mad24s(fw[0], R, half))) >> LAB_SHIFT];
+    const int fY = L.cbrt[d_mad24s(fw[5], B, d_mad24s(fw[4], G, d_mad24s(fw[3], R, half))) >> LAB_SHIFT];
+    const int fZ = L.cbrt[d_mad24s(fw[8], B, d_mad24s(fw[7], G, d_mad24s(fw[6], R, half))) >> LAB_SHIFT];
     oL = d_sat8(D_DESCALE(Lscale * fY + Lshift, LAB_SHIFT2));
     const int oa = d_sat8(D_DESCALE(500 * (fX - fY) + 128 * (1 << LAB_SHIFT2), LAB_SHIFT2));
     const int ob = d_sat8(D_DESCALE(200 * (fY - fZ) + 128 * (1 << LAB_SHIFT2), LAB_SHIFT2));
@@ -111,7 +122,6 @@ __global__ __launch_bounds__(256) void k_color_lab_hist(const u8* __restrict__ s
     lds_copy(L.hdiv, st->hdiv, sizeof(L.hdiv));
     lds_copy(L.cbrt, st->cbrt, sizeof(L.cbrt));
     lds_copy(L.gamma, st->gamma, sizeof(L.gamma));
-    if (threadIdx.x < 9) L.fwd[threadIdx.x] = st->fwd[threadIdx.x];
     lds_copy(&L.pt, pt, sizeof(ProfileTabs));
     for (int i = threadIdx.x; i < 256 * 8; i += blockDim.x) L.hist[i] = 0;
     __syncthreads();
@@ -128,6 +138,9 @@ __global__ __launch_bounds__(256) void k_color_lab_hist(const u8* __restrict__ s
     const bool aligned = ((cg.tw & 3) == 0) && ((g.stride & 3) == 0);
     const int groups = (cg.tw + 3) >> 2;
     const bool radical = L.pt.radical != 0;
+    int fw[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) fw[i] = st->fwd[i];
     const u32 hist_lane = (u32)(lane & 7) << 29; // v_alignbit(L, hist_lane, 27) = (L << 5) | (lane & 7) << 2: byte address of the copy
 
     for (int rr = r0 + wave; rr < r1; rr += 4) {
@@ -146,7 +159,7 @@ __global__ __launch_bounds__(256) void k_color_lab_hist(const u8* __restrict__ s
             }
             if (do_lab) {
                 int oL;
-                v = d_bgr2lab_px(L, b, gg, r, oL);
+                v = d_bgr2lab_px(L, fw, b, gg, r, oL);
                 atomicAdd((u32*)((u8*)L.hist + __builtin_amdgcn_alignbit((u32)oL, hist_lane, 27)), 1u);
             }
             return v;
@@ -300,6 +313,7 @@ __device__ __forceinline__ int d_ab_to_xz(int i)
     return i * i / LAB_BASE * i / LAB_BASE;
 }
 
+#define IFY_BIAS (128 * LAB_BASE / 200 - 1) // bdiv = ((b * 41943 + 16) >> 9) - IFY_BIAS
 #define CLAHE_MAX_TILES_X 32
 // RG = false: the whole-frame launch, with the region code compiled out
 // Register budget: 48 VGPRs.  Three of its waves then fit beside the three 120-register waves a 768-lane bilateral
@@ -316,7 +330,9 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const u8* __restrict__ lab,
     if (RG && sat_gate_closed(gate, blockIdx.z)) return;
     // static LDS: table addresses become ds_read immediates (no per-lookup base add)
     __shared__ u8 inv_gamma[INV_GAMMA_TAB_SIZE]; // sRGBInvGammaTab_b as bytes (every entry is <= 255): the index IS the address
-    __shared__ u32 lab_yf[256];          // y | ify << 16: one gather for the pair
+    __shared__ u32 lab_yf[256];          // y | (ify + IFY_BIAS) << 16, read back as two u16 at one address register
+    __shared__ u16 adiv_t[256];          // (5 a 53687 + 2^7) >> 13
+    __shared__ u16 bdiv_t[256];          // (b 41943 + 2^4) >> 9
     extern __shared__ __align__(16) u32 pk[]; // [tiles_x + 1][256]: this band's packed corner words (k_clahe_lut)
 
     // band b holds the rows whose unclamped ty1 is b - 1
@@ -341,7 +357,13 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const u8* __restrict__ lab,
     const int gx0 = cov.x0 >> 2, gx1 = (cov.x1 + 3) >> 2;
 
     for (int i = threadIdx.x; i < INV_GAMMA_TAB_SIZE; i += blockDim.x) inv_gamma[i] = (u8)st->inv_gamma[i];
-    lds_copy(lab_yf, st->lab_yf, 1024); // u16 pairs (y, ify) read back as one word
+    // u16 pairs (y, ify) as one word; ify is stored with the constant of `ify - bdiv` already added (it fits 16 bits:
+    // ify <= LAB_BASE * 1.01), so that argument costs one subtraction per pixel and the other one three-way add
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+        lab_yf[i] = (u32)st->lab_yf[2 * i] | ((u32)(st->lab_yf[2 * i + 1] + IFY_BIAS) << 16);
+        adiv_t[i] = (u16)((5 * i * 53687 + (1 << 7)) >> 13); // <= 8356
+        bdiv_t[i] = (u16)((i * 41943 + (1 << 4)) >> 9);      // <= 20889
+    }
     // Lab2RGBinteger's nine coefficients: uniform loads, they stay in scalar registers
     int invc[9];
 #pragma unroll
@@ -371,20 +393,23 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const u8* __restrict__ lab,
     // per-pixel predicate: their gathers overlap).
     // 1: CLAHE's bilinear interpolation between the four corner LUTs on L, then the arguments of Lab2RGBinteger's two
     //    ab -> xz conversions
-    auto px_front = [&](int v, int aa, int bb, int opk, float xak, float ya, float ya1, int& yv, int& ix, int& iz) {
+    //    (v4 = 4 L, a2 = 2 a, b2 = 2 b: byte offsets into the tables, formed by the caller with one shift and one mask
+    //    each, both full-rate instructions; a bit-field extract and a shift are both half-rate)
+    auto px_front = [&](u32 v4, u32 a2, u32 b2, int opk, float xak, float ya, float ya1, int& yv, int& ix, int& iz) {
         const float xa1k = 1.0f - xak; // (recomputed per pixel: one instruction against a register held across the rows)
-        const u32 cw = *(const u32*)((const u8*)pk + opk + v * 4); // the four corner LUT values of L = v
+        const u32 cw = *(const u32*)((const u8*)pk + opk + v4); // the four corner LUT values of L
         float ra = (float)(cw & 255u) * xa1k + (float)((cw >> 8) & 255u) * xak;
         float rb = (float)((cw >> 16) & 255u) * xa1k + (float)(cw >> 24) * xak;
         float res = ra * ya1 + rb * ya;
         const int LL = (int)__builtin_amdgcn_cvt_pk_u8_f32(res, 0, 0u); // round-half-even + saturate
-        const u32 yf = lab_yf[LL];
-        yv = (int)(yf & 0xFFFFu);
-        const int ify = (int)(yf >> 16);
-        const int adiv = ((5 * aa * 53687 + (1 << 7)) >> 13) - 128 * LAB_BASE / 500;
-        const int bdiv = ((bb * 41943 + (1 << 4)) >> 9) - 128 * LAB_BASE / 200 + 1;
-        ix = ify + adiv;
-        iz = ify - bdiv;
+        // LDS has room in this kernel (a third of the vector pipe's time): y and ify as two 16-bit reads, adiv / bdiv as
+        // table reads instead of a multiply-add and a shift each
+        const u16* yfp = (const u16*)((const u8*)lab_yf + LL * 4);
+        yv = (int)yfp[0];
+        const int ifyb = (int)yfp[1]; // ify + IFY_BIAS
+        // adiv = adiv_t[a] - 128 LAB_BASE / 500, bdiv = bdiv_t[b] - IFY_BIAS
+        ix = ifyb + (int)*(const u16*)((const u8*)adiv_t + a2) - (128 * LAB_BASE / 500 + IFY_BIAS);
+        iz = ifyb - (int)*(const u16*)((const u8*)bdiv_t + b2);
     };
     // 2: d_ab_to_xz.  Its cubic branch (i > 3390, i.e. f(t) above 6/29: every pixel that is not nearly black in that
     //    coordinate) is evaluated for all lanes; the linear branch costs more instructions than the cubic one and is
@@ -396,9 +421,12 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const u8* __restrict__ lab,
     // 3: the inverse matrix, the inverse gamma table, packing
     auto px_back = [&](int xv, int yv, int zv) -> u32 {
         // |x|,|y|,|z| < 2^17 and |coefficient| < 2^14: 24-bit multiplies are exact
-        int ro = D_DESCALE(__mul24(invc[0], xv) + __mul24(invc[1], yv) + __mul24(invc[2], zv), shift);
-        int go = D_DESCALE(__mul24(invc[3], xv) + __mul24(invc[4], yv) + __mul24(invc[5], zv), shift);
-        int bo = D_DESCALE(__mul24(invc[6], xv) + __mul24(invc[7], yv) + __mul24(invc[8], zv), shift);
+        // (a chain of three multiply-adds that starts from the rounding constant: 3 instructions a channel; left to itself
+        // hipcc forms two products and a three-way add, 4 instructions)
+        const int half = 1 << (shift - 1);
+        int ro = d_mad24s(invc[2], zv, d_mad24s(invc[1], yv, d_mad24s(invc[0], xv, half))) >> shift;
+        int go = d_mad24s(invc[5], zv, d_mad24s(invc[4], yv, d_mad24s(invc[3], xv, half))) >> shift;
+        int bo = d_mad24s(invc[8], zv, d_mad24s(invc[7], yv, d_mad24s(invc[6], xv, half))) >> shift;
         ro = min(max(ro, 0), INV_GAMMA_TAB_SIZE - 1);
         go = min(max(go, 0), INV_GAMMA_TAB_SIZE - 1);
         bo = min(max(bo, 0), INV_GAMMA_TAB_SIZE - 1);
@@ -406,7 +434,7 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const u8* __restrict__ lab,
     };
     auto do_px = [&](int v, int aa, int bb, int opk, float xak, float ya, float ya1) -> u32 {
         int yv, ix, iz;
-        px_front(v, aa, bb, opk, xak, ya, ya1, yv, ix, iz);
+        px_front((u32)v * 4, (u32)aa * 2, (u32)bb * 2, opk, xak, ya, ya1, yv, ix, iz);
         return px_back(d_ab_to_xz(ix), yv, d_ab_to_xz(iz));
     };
     // one group of one row
@@ -422,7 +450,7 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const u8* __restrict__ lab,
             const u32 d0 = pw[0], d1 = pw[1], d2 = pw[2];
             // bytes: L0 a0 b0 L1 | a1 b1 L2 a2 | b2 L3 a3 b3
             // two pixels at a time: enough independent work to overlap the gathers, few enough live values for 48 VGPRs
-            auto pair = [&](int v0, int a0, int b0, int v1, int a1, int b1, int k0, u32& Pa, u32& Pb) {
+            auto pair = [&](u32 v0, u32 a0, u32 b0, u32 v1, u32 a1, u32 b1, int k0, u32& Pa, u32& Pb) {
                 int yv0, ix0, iz0, yv1, ix1, iz1;
                 px_front(v0, a0, b0, op[k0], xa[k0], ya, ya1, yv0, ix0, iz0);
                 px_front(v1, a1, b1, op[k0 + 1], xa[k0 + 1], ya, ya1, yv1, ix1, iz1);
@@ -437,8 +465,8 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const u8* __restrict__ lab,
                 Pb = px_back(xv1, yv1, zv1);
             };
             u32 P0, P1, P2, P3;
-            pair(d0 & 255u, (d0 >> 8) & 255u, (d0 >> 16) & 255u, d0 >> 24, d1 & 255u, (d1 >> 8) & 255u, 0, P0, P1);
-            pair((d1 >> 16) & 255u, d1 >> 24, d2 & 255u, (d2 >> 8) & 255u, (d2 >> 16) & 255u, d2 >> 24, 2, P2, P3);
+            pair((d0 << 2) & 0x3FCu, (d0 >> 7) & 0x1FEu, (d0 >> 15) & 0x1FEu, (d0 >> 22) & 0x3FCu, (d1 << 1) & 0x1FEu, (d1 >> 7) & 0x1FEu, 0, P0, P1);
+            pair((d1 >> 14) & 0x3FCu, (d1 >> 23) & 0x1FEu, (d2 << 1) & 0x1FEu, (d2 >> 6) & 0x3FCu, (d2 >> 15) & 0x1FEu, (d2 >> 23) & 0x1FEu, 2, P2, P3);
             u32* qw = (u32*)q;
             qw[0] = __builtin_amdgcn_perm(P1, P0, 0x04020100u);
             qw[1] = __builtin_amdgcn_perm(P2, P1, 0x05040201u);
