@@ -389,7 +389,7 @@ def class_api_leg(frames, w, h, pts, grid, profile, detector_kw, frames_per_ply=
         out[name] = med(t_total)
         out[name.replace("_ms", "_breakdown_ms")] = {"process_pipeline": med(t_enh) if with_enhance else None, "warp_image": med(t_warp),
                                                       "split_board": med(t_split), "detect_all_pieces": med(t_det),
-                                                      "worst_frame": round(max(t_total) * 1e3, 4)}
+                                                      "best_frame": round(min(t_total) * 1e3, 4), "worst_frame": round(max(t_total) * 1e3, 4)}
     out["frames"] = len(frames)
     out["occupancy_check"] = bool(ok)
     out["note"] = ("the reference's own per-frame calls through the drop-in classes (game_session.py:124-161), one %dx%d numpy frame at a time, "
