@@ -777,6 +777,9 @@ extern "C" void cbv_squares_destroy(cbv_squares* s)
     delete s;
 }
 
+// np.sqrt(var) of every pixel, kept beside the variance plane by the kernels that write it
+static float* sq_sd(cbv_squares* s) { return (float*)s->d_var.p + s->plane_total; }
+
 static int squares_set_coef(cbv_squares* s, int blur_k)
 {
     cbv_ctx* ctx = s->ctx;
@@ -823,7 +826,7 @@ static int squares_set_geometry(cbv_squares* s, const int* ws, const int* hs, in
     RC(dev_ensure(ctx, &s->d_gray, off));
     RC(dev_ensure(ctx, &s->d_ref, off));
     RC(dev_ensure(ctx, &s->d_mean, off * 4));
-    RC(dev_ensure(ctx, &s->d_var, off * 4));
+    RC(dev_ensure(ctx, &s->d_var, off * 8)); // variance plane, then its square root (sq_sd)
     RC(dev_ensure(ctx, &s->d_stats, sizeof(cbv_sq_stats) * n));
     RC(dev_ensure(ctx, &s->d_select, CBV_MAX_SQUARES * 4));
     RC(dev_ensure(ctx, &s->d_descs, sizeof(SquareDesc) * n));
@@ -933,7 +936,7 @@ extern "C" int cbv_squares_calibrate(cbv_squares* s, double initial_variance, co
     const u8* sel;
     RC(squares_select(s, select, &sel));
     RC(launch_squares_calibrate(ctx, (const SquareDesc*)s->d_descs.p, s->n, (const u8*)s->d_gray.p, (float*)s->d_mean.p, (float*)s->d_var.p,
-                                (float)initial_variance, sel));
+                                sq_sd(s), (float)initial_variance, sel));
     CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     s->has_model = true;
     return CBV_OK;
@@ -947,7 +950,7 @@ extern "C" int cbv_squares_ema(cbv_squares* s, double alpha, const uint8_t* sele
     CBV_ENTER(ctx);
     const u8* sel;
     RC(squares_select(s, select, &sel));
-    RC(launch_squares_ema(ctx, (const SquareDesc*)s->d_descs.p, s->n, (const u8*)s->d_gray.p, (float*)s->d_mean.p, (float*)s->d_var.p, alpha, sel));
+    RC(launch_squares_ema(ctx, (const SquareDesc*)s->d_descs.p, s->n, (const u8*)s->d_gray.p, (float*)s->d_mean.p, (float*)s->d_var.p, sq_sd(s), alpha, sel));
     CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return CBV_OK;
 }
@@ -974,7 +977,7 @@ extern "C" int cbv_squares_stats(cbv_squares* s, int use_ref, int use_model, dou
     if (use_model && !s->has_model) return cbv_fail(ctx, CBV_ERR_STATE, "cbv_squares_stats: model requested but not calibrated");
     CBV_ENTER(ctx);
     RC(launch_squares_stats(ctx, (const SquareDesc*)s->d_descs.p, s->n, (const u8*)s->d_gray.p, 0, use_ref ? (const u8*)s->d_ref.p : nullptr,
-                            use_model ? (const float*)s->d_mean.p : nullptr, use_model ? (const float*)s->d_var.p : nullptr,
+                            use_model ? (const float*)s->d_mean.p : nullptr, use_model ? (const float*)sq_sd(s) : nullptr,
                             (const u8*)s->d_masks.p, (float)z_threshold, (cbv_sq_stats*)s->d_stats.p, 1));
     CBV_HIP(ctx, hipMemcpyAsync(out, s->d_stats.p, sizeof(cbv_sq_stats) * s->n, hipMemcpyDeviceToHost, ctx->stream));
     CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1303,7 +1306,7 @@ extern "C" int cbv_squares_detect_changes(cbv_squares* s, const cbv_host_image* 
     const bool five = s->blur_k == 5;
     if (five) {
         RC(launch_squares_pre5_stats(ctx, (const u8*)s->d_stage.p, 0, (const SquareDesc*)s->d_descs.p, n, (u8*)s->d_gray.p, 0, (const float*)s->d_mean.p,
-                                     (const float*)s->d_var.p, (const u8*)s->d_masks.p, (float)prm->z_threshold, L.stats, 1, nullptr, 0, nullptr, nullptr,
+                                     (const float*)sq_sd(s), (const u8*)s->d_masks.p, (float)prm->z_threshold, L.stats, 1, nullptr, 0, nullptr, nullptr,
                                      mpx));
     } else {
         // the detector's own blur for the background model, and the squares as PieceDetector preprocesses them (k = 5)
@@ -1311,7 +1314,7 @@ extern "C" int cbv_squares_detect_changes(cbv_squares* s, const cbv_host_image* 
         RC(launch_squares_preprocess(ctx, (const u8*)s->d_stage.p, 0, (const SquareDesc*)s->d_descs.p, n, (const int*)s->d_coef.p, s->blur_k,
                                      (u8*)s->d_gray.p, 0, 1, mpx));
         RC(launch_squares_stats(ctx, (const SquareDesc*)s->d_descs.p, n, (const u8*)s->d_gray.p, 0, nullptr, (const float*)s->d_mean.p,
-                                (const float*)s->d_var.p, (const u8*)s->d_masks.p, (float)prm->z_threshold, L.stats, 1));
+                                (const float*)sq_sd(s), (const u8*)s->d_masks.p, (float)prm->z_threshold, L.stats, 1));
         RC(dev_ensure(ctx, &s->d_gray5, s->plane_total));
         RC(launch_squares_pre5_stats(ctx, (const u8*)s->d_stage.p, 0, (const SquareDesc*)s->d_descs.p, n, (u8*)s->d_gray5.p, 0, nullptr, nullptr,
                                      (const u8*)s->d_masks.p, 0.f, L.stats5, 1, nullptr, 0, nullptr, nullptr, mpx));
@@ -1377,6 +1380,7 @@ static int squares_plane(cbv_squares* s, int which, int index, void** p, size_t*
     case 1: *p = (u8*)s->d_ref.p + d.plane_off; *bytes = n; break;
     case 2: *p = (float*)s->d_mean.p + d.plane_off; *bytes = n * 4; break;
     case 3: *p = (float*)s->d_var.p + d.plane_off; *bytes = n * 4; break;
+    case 4: *p = sq_sd(s) + d.plane_off; *bytes = n * 4; break; // sqrt(var) as the statistics kernels read it (inspection)
     default: return cbv_fail(ctx, CBV_ERR_ARG, "bad plane selector %d", which);
     }
     return CBV_OK;
@@ -1404,6 +1408,7 @@ extern "C" int cbv_squares_set(cbv_squares* s, int which, int index, const void*
     RC(squares_plane(s, which, index, &p, &bytes));
     CBV_ENTER(ctx);
     CBV_HIP(ctx, hipMemcpyAsync(p, in, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (which == 3) RC(launch_squares_refresh_sd(ctx, (const SquareDesc*)s->d_descs.p, (const float*)s->d_var.p, sq_sd(s), index));
     CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (which == 1) s->has_ref = true;
     return CBV_OK;
@@ -1680,7 +1685,7 @@ extern "C" int cbv_pipeline_configure(cbv_pipeline* p, const cbv_pipeline_config
     RC(dev_ensure(ctx, &p->d_stats, sizeof(cbv_sq_stats) * n * p->max_frames));
     RC(dev_ensure(ctx, &p->d_ref, off));
     RC(dev_ensure(ctx, &p->d_mean, off * 4));
-    RC(dev_ensure(ctx, &p->d_var, off * 4));
+    RC(dev_ensure(ctx, &p->d_var, off * 8)); // variance plane, then its square root
     p->calibrated = false;
     RC(dev_ensure(ctx, &p->d_state, sizeof(ScanState) * n));
     RC(dev_ensure(ctx, &p->d_results, sizeof(cbv_frame_result) * p->max_frames));
@@ -1733,7 +1738,7 @@ extern "C" int cbv_pipeline_calibrate(cbv_pipeline* p, int slot)
     CBV_ENTER(ctx);
     RC(join_scan(p)); // lanes and scan of the last run
     RC(launch_squares_calibrate(ctx, (const SquareDesc*)p->d_descs.p, p->cfg.n_rois, (const u8*)p->d_gray.p + p->plane_total * slot,
-                                (float*)p->d_mean.p, (float*)p->d_var.p, (float)p->cfg.initial_variance, nullptr));
+                                (float*)p->d_mean.p, (float*)p->d_var.p, (float*)p->d_var.p + p->plane_total, (float)p->cfg.initial_variance, nullptr));
     p->calibrated = true;
     return CBV_OK;
 }
@@ -1932,7 +1937,7 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
         cbv_hough_result* hres = cfg.use_hough ? (cbv_hough_result*)p->d_hough.p + (size_t)CBV_MAX_SQUARES * s0 : nullptr;
         rc_all = launch_squares_pre5_stats(ctx, wdst, p->warped_stride, (const SquareDesc*)p->d_descs.p, n,
                                            (u8*)p->d_gray.p + p->plane_total * s0, p->plane_total,
-                                           p->calibrated ? (const float*)p->d_mean.p : nullptr, p->calibrated ? (const float*)p->d_var.p : nullptr,
+                                           p->calibrated ? (const float*)p->d_mean.p : nullptr, p->calibrated ? (const float*)p->d_var.p + p->plane_total : nullptr,
                                            (const u8*)p->d_masks.p, (float)cfg.z_threshold, (cbv_sq_stats*)p->d_stats.p + (size_t)n * s0, b,
                                            dec, cfg.use_hough, work, hres, p->max_px);
         if (rc_all) break;

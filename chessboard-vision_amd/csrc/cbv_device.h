@@ -10,6 +10,20 @@ __device__ __forceinline__ int d_round_d(double v) { return __double2int_rn(v); 
 __device__ __forceinline__ u8 d_sat8(int v) { return (u8)min(max(v, 0), 255); }
 __device__ __forceinline__ u8 d_sat8_f(float v) { return d_sat8(d_round_f(v)); }
 
+// Correctly rounded float32 square root (np.sqrt on float32), spelled out: v_sqrt_f32 is good to 1 ulp, the two residuals
+// decide between the result and its neighbours.  Not left to `__fsqrt_rn`: hipcc expands that to this very sequence in
+// one kernel and to the bare instruction in another (k_squares_ema, where a quarter of the results were 1 ulp off).
+// Zero, infinity and NaN pass through (every comparison with the NaN residuals is false); x is a normal number otherwise.
+__device__ __forceinline__ float d_sqrt_rn(float x)
+{
+    float y = __builtin_amdgcn_sqrtf(x);
+    const float ym = __int_as_float(__float_as_int(y) - 1), yp = __int_as_float(__float_as_int(y) + 1);
+    const float rm = __fmaf_rn(-ym, y, x), rp = __fmaf_rn(-yp, y, x);
+    if (rm <= 0.f) y = ym;
+    if (rp > 0.f) y = yp;
+    return y;
+}
+
 // cv::borderInterpolate(p, len, BORDER_REFLECT_101)
 __device__ __forceinline__ int d_reflect101(int p, int len)
 {

@@ -366,10 +366,12 @@ int launch_squares_pre5_stats(cbv_ctx* ctx, const u8* src, size_t src_frame_stri
                               size_t gray_frame_stride, const float* mean, const float* var, const u8* masks, float z_thresh,
                               cbv_sq_stats* out, int batch, u8* decisions, int want_hough, u32* hough_work,
                               cbv_hough_result* hough_out, int max_px, const u8* ref = nullptr, const DetectMasks* dm = nullptr);
-int launch_squares_calibrate(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, float* mean, float* var,
+// (the statistics launchers' `var` argument is the SD plane: sqrt(var), written by these three next to the variance)
+int launch_squares_calibrate(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, float* mean, float* var, float* sd,
                              float init_var, const u8* select);
-int launch_squares_ema(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, float* mean, float* var,
+int launch_squares_ema(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, float* mean, float* var, float* sd,
                        double alpha, const u8* select);
+int launch_squares_refresh_sd(cbv_ctx* ctx, const SquareDesc* descs, const float* var, float* sd, int index);
 int launch_squares_set_ref(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, u8* ref, const u8* select);
 int launch_squares_set_ref_mask(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, u8* ref, u64 mask);
 

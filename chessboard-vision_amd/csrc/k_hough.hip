@@ -314,7 +314,7 @@ __global__ __launch_bounds__(HG_NT) void k_hough(const SquareDesc* __restrict__ 
         int ix, iy;
         hg_sobel(g, gs, x, y, ix, iy);
         const float vx = (float)ix, vy = (float)iy;
-        const float mg = __fsqrt_rn(vx * vx + vy * vy);
+        const float mg = d_sqrt_rn(vx * vx + vy * vy);
         int sx = d_round_f((vx * idp) * 1024.f / mg);
         int sy = d_round_f((vy * idp) * 1024.f / mg);
         if (t & 1) {
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(HG_NT) void k_hough(const SquareDesc* __restrict__ 
                 const float ex = ccx - (float)(edges[j] & 255), ey = ccy - (float)(edges[j] >> 8);
                 const float r2 = ex * ex + ey * ey;
                 if (minR2 <= r2 && r2 <= maxR2) {
-                    const int bin = max(0, min(nbins - 1, d_round_f((__fsqrt_rn(r2) - min_radius) / dp * 10)));
+                    const int bin = max(0, min(nbins - 1, d_round_f((d_sqrt_rn(r2) - min_radius) / dp * 10)));
                     atomicAdd(&mybins[bin], 1);
                 }
             }
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(HG_NT) void k_hough(const SquareDesc* __restrict__ 
         kept = __popcll(am);
         const int pos = __popcll(am & ((1ull << lane) - 1ull)); // index among the survivors
         const float ex = me.x - (float)(w / 2), ey = me.y - (float)(h / 2);
-        const float dist = __fsqrt_rn(ex * ex + ey * ey);
+        const float dist = d_sqrt_rn(ex * ex + ey * ey);
         const bool cand = alive && dist < max_off;
         float best = cand ? dist : __builtin_inff();
 #pragma unroll
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(HG_NT) void k_hough(const SquareDesc* __restrict__ 
         for (int i = 0; i < kept; i++) {
             const HgCircle ci = sorted[i];
             const float ex = ci.x - (float)(w / 2), ey = ci.y - (float)(h / 2);
-            const float dist = __fsqrt_rn(ex * ex + ey * ey);
+            const float dist = d_sqrt_rn(ex * ex + ey * ey);
             if (dist < max_off && dist < best) {
                 best = dist;
                 pick = i;

@@ -198,7 +198,10 @@ __device__ __forceinline__ void sq_accum_init(SqAccum& A)
     A.nan_seen = 0;
 }
 
-__device__ __forceinline__ void sq_accum_px(SqAccum& A, int gv, u32 mk, bool has_ref, int refv, bool has_model, float mu, float va,
+// sd = np.sqrt(var) of the pixel, float32 correctly rounded: it does not depend on the frame, so the kernels that write
+// the variance plane (calibrate, EMA, a plane set by the host) store it beside the variance and the statistics kernels
+// read it instead of taking the square root per pixel and frame
+__device__ __forceinline__ void sq_accum_px(SqAccum& A, int gv, u32 mk, bool has_ref, int refv, bool has_model, float mu, float sd,
                                             float z_thresh)
 {
     A.v[0] += gv;
@@ -214,8 +217,7 @@ __device__ __forceinline__ void sq_accum_px(SqAccum& A, int gv, u32 mk, bool has
         A.v[11 + k] += (mk >> (2 + k)) & 1;
     }
     if (has_model) {
-        // change_detector.py:131-137 in float32: sqrt and division are IEEE-rounded
-        const float sd = __fsqrt_rn(va);
+        // change_detector.py:131-137 in float32: sqrt (stored) and division are IEEE-rounded
         const float df = fabsf((float)gv - mu);
         const float z = __fdiv_rn(df, sd);
         if (z > z_thresh) A.v[15]++;
@@ -461,20 +463,36 @@ int launch_squares_stats(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8*
 
 // ---------------------------------------------------------------------------
 __global__ void k_squares_calibrate(const SquareDesc* __restrict__ descs, const u8* __restrict__ gray,
-                                    float* __restrict__ mean, float* __restrict__ var, float init_var,
+                                    float* __restrict__ mean, float* __restrict__ var, float* __restrict__ sd, float init_var,
                                     const u8* __restrict__ select)
 {
     if (select && !select[blockIdx.x]) return;
     const SquareDesc d = descs[blockIdx.x];
+    const float isd = d_sqrt_rn(init_var);
     for (int i = threadIdx.x; i < d.w * d.h; i += blockDim.x) {
         mean[d.plane_off + i] = (float)gray[d.plane_off + i];
         var[d.plane_off + i] = init_var;
+        sd[d.plane_off + i] = isd;
     }
+}
+
+// sd plane of one square after the host wrote its variance plane (cbv_squares_set)
+__global__ void k_squares_refresh_sd(const SquareDesc* __restrict__ descs, const float* __restrict__ var, float* __restrict__ sd, int index)
+{
+    const SquareDesc d = descs[index];
+    for (int i = threadIdx.x; i < d.w * d.h; i += blockDim.x) sd[d.plane_off + i] = d_sqrt_rn(var[d.plane_off + i]);
+}
+
+int launch_squares_refresh_sd(cbv_ctx* ctx, const SquareDesc* descs, const float* var, float* sd, int index)
+{
+    hipLaunchKernelGGL(k_squares_refresh_sd, dim3(1), dim3(256), 0, ctx->stream, descs, var, sd, index);
+    CBV_HIP(ctx, hipGetLastError());
+    return CBV_OK;
 }
 
 // update_all_references (change_detector.py:77-92), float32, one rounding per op
 __global__ void k_squares_ema(const SquareDesc* __restrict__ descs, const u8* __restrict__ gray,
-                              float* __restrict__ mean, float* __restrict__ var, float one_minus, float alpha,
+                              float* __restrict__ mean, float* __restrict__ var, float* __restrict__ sd, float one_minus, float alpha,
                               const u8* __restrict__ select)
 {
     if (select && !select[blockIdx.x]) return;
@@ -492,6 +510,7 @@ __global__ void k_squares_ema(const SquareDesc* __restrict__ descs, const u8* __
         if (!(nv >= 10.0f)) nv = (nv != nv) ? nv : 10.0f; // np.maximum propagates NaN
         mean[d.plane_off + i] = nm;
         var[d.plane_off + i] = nv;
+        sd[d.plane_off + i] = d_sqrt_rn(nv);
     }
 }
 
@@ -524,20 +543,20 @@ int launch_scan_update_refs(cbv_ctx* ctx, const SquareDesc* descs, int n, const 
     return CBV_OK;
 }
 
-int launch_squares_calibrate(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, float* mean, float* var,
+int launch_squares_calibrate(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, float* mean, float* var, float* sd,
                              float init_var, const u8* select)
 {
-    hipLaunchKernelGGL(k_squares_calibrate, dim3(n), dim3(256), 0, ctx->stream, descs, gray, mean, var, init_var, select);
+    hipLaunchKernelGGL(k_squares_calibrate, dim3(n), dim3(256), 0, ctx->stream, descs, gray, mean, var, sd, init_var, select);
     CBV_HIP(ctx, hipGetLastError());
     return CBV_OK;
 }
 
-int launch_squares_ema(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, float* mean, float* var,
+int launch_squares_ema(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, float* mean, float* var, float* sd,
                        double alpha, const u8* select)
 {
     // (1 - self.alpha) and self.alpha are python doubles turned float32 by numpy (weak scalars)
     float one_minus = (float)(1.0 - alpha), a = (float)alpha;
-    hipLaunchKernelGGL(k_squares_ema, dim3(n), dim3(256), 0, ctx->stream, descs, gray, mean, var, one_minus, a, select);
+    hipLaunchKernelGGL(k_squares_ema, dim3(n), dim3(256), 0, ctx->stream, descs, gray, mean, var, sd, one_minus, a, select);
     CBV_HIP(ctx, hipGetLastError());
     return CBV_OK;
 }

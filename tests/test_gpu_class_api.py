@@ -335,3 +335,32 @@ def test_session_loop_example_recognises_the_scripted_game(gpu_ctx):
     assert [l.split()[2] for l in lines] == ["e2e4", "e7e5", "g1f3", "b8c6", "f1b5", "a7a6", "b5a4", "g8f6", "e1g1", "f8e7", "f1e1",
                                              "b7b5", "a4b3", "d7d6", "c2c3", "e8g8"]
     assert "final FEN r1bq1rk1/2p1bppp/p1np1n2/1p2p3/4P3/1BP2N2/PP1P1PPP/RNBQR1K1 w - - 1 9" in r.stdout
+
+
+def test_planes_written_by_the_host_take_effect(gpu_ctx, oracle):
+    """`detector.variances[pos] = array` / `means[pos] = array` (the dict-like views write the device planes): the
+    statistics kernels read sqrt(variance) from a plane kept beside the variance, so a variance written by the host must
+    refresh it (correctly rounded: np.sqrt on float32, bit for bit)."""
+    from chessboard_vision_amd.board_detection import warp_image
+    from chessboard_vision_amd.change_detector import ChangeDetector
+    from ref_logic import RefChangeDetector
+    pts = S.scaled_corners(W, H)
+    ge = _grid("linear")
+    a = ge.split_board(warp_image(oracle_frame(W, H, "normal", frame_idx=0), pts)[0])
+    b = ge.split_board(warp_image(oracle_frame(W, H, "normal", frame_idx=5, frames_per_ply=1), pts)[0])
+    cd, ref = ChangeDetector(), RefChangeDetector(hough={})
+    cd.calibrate(a)
+    ref.calibrate(a)
+    rng = np.random.default_rng(3)
+    for pos in list(a)[::3]:
+        v = rng.uniform(10.0, 900.0, a[pos].shape[:2]).astype(np.float32)
+        m = rng.uniform(0.0, 255.0, a[pos].shape[:2]).astype(np.float32)
+        cd.variances[pos] = v
+        cd.means[pos] = m
+        ref.variances[pos] = v.copy()
+        ref.means[pos] = m.copy()
+    got, want = cd.detect_changes_detailed(b), ref.detect_changes_detailed(b)
+    assert got == want and len(got) > 20
+    cd.update_all_references(b)
+    ref.update_all_references(b)
+    assert cd.detect_changes_detailed(a) == ref.detect_changes_detailed(a)
