@@ -821,7 +821,10 @@ static int squares_set_geometry(cbv_squares* s, const int* ws, const int* hs, in
     s->plane_total = off;
     s->has_ref = s->has_model = false;
     std::vector<u8> masks(off, 0);
-    for (int i = 0; i < n; i++) build_piece_mask(ws[i], hs[i], masks.data() + s->descs[i].mask_off);
+    for (int i = 0; i < n; i++) {
+        build_piece_mask(ws[i], hs[i], masks.data() + s->descs[i].mask_off);
+        square_region_counts(masks.data() + s->descs[i].mask_off, ws[i] * hs[i], s->descs[i].cnt);
+    }
     RC(dev_ensure(ctx, &s->d_masks, off));
     RC(dev_ensure(ctx, &s->d_gray, off));
     RC(dev_ensure(ctx, &s->d_ref, off));
@@ -1240,7 +1243,7 @@ extern "C" int cbv_squares_detect_all(cbv_squares* s, const cbv_host_image* img,
     CBV_ENTER(ctx);
     RC(hough_params_check(ctx, &prm->hough)); // before anything of the set changes
     u8* hst;
-    const size_t o_back = 4096; // the descriptors are staged in front of it
+    const size_t o_back = 8192; // the descriptors (64 x 64 B) are staged in front of it
     RC(ctx_hstage(ctx, 65536, &hst));
     FastLayout L;
     RC(fast_layout(s, &L));
@@ -1295,7 +1298,7 @@ extern "C" int cbv_squares_detect_changes(cbv_squares* s, const cbv_host_image* 
     CBV_ENTER(ctx);
     RC(hough_params_check(ctx, &prm->hough));
     u8* hst;
-    const size_t o_back = 4096, o_wk = 40960;
+    const size_t o_back = 8192, o_wk = 40960;
     RC(ctx_hstage(ctx, 65536, &hst));
     const int old_n = s->n;
     RC(squares_stage_host_image(s, img, rois, n, blur_k, hst));
@@ -1678,7 +1681,10 @@ extern "C" int cbv_pipeline_configure(cbv_pipeline* p, const cbv_pipeline_config
     p->max_px = 0;
     for (int i = 0; i < n; i++) p->max_px = std::max(p->max_px, p->descs[i].w * p->descs[i].h);
     std::vector<u8> masks(off, 0);
-    for (int i = 0; i < n; i++) build_piece_mask(p->descs[i].w, p->descs[i].h, masks.data() + p->descs[i].mask_off);
+    for (int i = 0; i < n; i++) {
+        build_piece_mask(p->descs[i].w, p->descs[i].h, masks.data() + p->descs[i].mask_off);
+        square_region_counts(masks.data() + p->descs[i].mask_off, p->descs[i].w * p->descs[i].h, p->descs[i].cnt);
+    }
     RC(dev_ensure(ctx, &p->d_descs, sizeof(SquareDesc) * n));
     RC(dev_ensure(ctx, &p->d_masks, off));
     RC(dev_ensure(ctx, &p->d_gray, off * p->max_frames));

@@ -320,7 +320,12 @@ struct SquareDesc {
     int plane_off; // element offset of this square's planes (gray/ref/mean/var)
     int mask_off;  // byte offset into the mask table
     int pad;
+    // pixels of each region of the square's mask (centre disc, corners, four rings): they depend on the square's shape
+    // only, so the host counts them once (square_region_counts) and the statistics kernels do not count them per frame
+    u32 cnt[6];
+    int pad2[2];
 };
+void square_region_counts(const u8* mask, int n, u32 cnt[6]);
 // detect_all_pieces' per-square gate for the class API (one frame), evaluated by thread 0 of the statistics kernels:
 // bit i of the sets = square i.  dflags == null: not a class-API launch.
 struct DetectMasks {

@@ -270,6 +270,13 @@ void build_piece_mask(int w, int h, u8* mask)
         }
 }
 
+void square_region_counts(const u8* mask, int n, u32 cnt[6])
+{
+    for (int k = 0; k < 6; k++) cnt[k] = 0;
+    for (int i = 0; i < n; i++)
+        for (int k = 0; k < 6; k++) cnt[k] += (mask[i] >> k) & 1u;
+}
+
 // cv::invert for a 3x3 double matrix (closed form), as warpPerspective uses
 // it when WARP_INVERSE_MAP is not set (board_detection.py:70).
 int host_invert3x3(const double* S, double* D)

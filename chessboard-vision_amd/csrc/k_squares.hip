@@ -207,15 +207,11 @@ __device__ __forceinline__ void sq_accum_px(SqAccum& A, int gv, u32 mk, bool has
     A.v[0] += gv;
     A.v[1] += gv * gv;
     if (has_ref) A.v[2] += (u32)abs(gv - refv);
+    // (the regions' pixel counts depend on the square's shape only: SquareDesc::cnt, counted once on the host)
     A.v[3] += (mk & 1) ? gv : 0;
-    A.v[4] += (mk & 1);
     A.v[5] += (mk & 2) ? gv : 0;
-    A.v[6] += (mk >> 1) & 1;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        A.v[7 + k] += (mk & (4u << k)) ? gv : 0;
-        A.v[11 + k] += (mk >> (2 + k)) & 1;
-    }
+    for (int k = 0; k < 4; k++) A.v[7 + k] += (mk & (4u << k)) ? gv : 0;
     if (has_model) {
         // change_detector.py:131-137 in float32: sqrt (stored) and division are IEEE-rounded
         const float df = fabsf((float)gv - mu);
@@ -231,10 +227,12 @@ __device__ __forceinline__ void sq_accum_px(SqAccum& A, int gv, u32 mk, bool has
 __device__ __forceinline__ void sq_accum_finish(SqAccum& A, u32* acc, float* zm, int* nanf_, int n, bool has_model,
                                                 cbv_sq_stats* __restrict__ out, int nsq, u8* __restrict__ decisions,
                                                 int want_hough, u32* __restrict__ hough_work,
-                                                cbv_hough_result* __restrict__ hough_out, const DetectMasks dm = DetectMasks())
+                                                cbv_hough_result* __restrict__ hough_out, const u32* __restrict__ cnt,
+                                                const DetectMasks dm = DetectMasks())
 {
 #pragma unroll
     for (int k = 0; k < 16; k++) {
+        if (k == 4 || k == 6 || (k >= 11 && k <= 14)) continue; // region counts come from the descriptor
         u32 s = wave_sum_u32(A.v[k]);
         if ((threadIdx.x & 63) == 0 && s) atomicAdd(&acc[k], s);
     }
@@ -249,12 +247,12 @@ __device__ __forceinline__ void sq_accum_finish(SqAccum& A, u32* acc, float* zm,
         st.sumsq = acc[1];
         st.sad_ref = acc[2];
         st.center_sum = acc[3];
-        st.center_cnt = acc[4];
+        st.center_cnt = cnt[0];
         st.border_sum = acc[5];
-        st.border_cnt = acc[6];
+        st.border_cnt = cnt[1];
         for (int k = 0; k < 4; k++) {
             st.ring_sum[k] = acc[7 + k];
-            st.ring_cnt[k] = acc[11 + k];
+            st.ring_cnt[k] = cnt[2 + k];
         }
         st.z_count = acc[15];
         float z = zm[0];
@@ -329,7 +327,7 @@ __global__ __launch_bounds__(256) void k_squares_stats(const SquareDesc* __restr
     for (int i = threadIdx.x; i < n; i += blockDim.x)
         sq_accum_px(A, g[i], m[i], ref != nullptr, ref ? (int)ref[d.plane_off + i] : 0, mean != nullptr,
                     mean ? mean[d.plane_off + i] : 0.f, mean ? var[d.plane_off + i] : 1.f, z_thresh);
-    sq_accum_finish(A, acc, zm, nanf_, n, mean != nullptr, out, nsq, decisions, want_hough, hough_work, hough_out, dm);
+    sq_accum_finish(A, acc, zm, nanf_, n, mean != nullptr, out, nsq, decisions, want_hough, hough_work, hough_out, descs[blockIdx.x].cnt, dm);
 }
 
 // preprocess (k = 5) and statistics of the pipeline in one pass: the statistics are sums over the plane the blur
@@ -421,7 +419,8 @@ __global__ __launch_bounds__(NT) void k_squares_pre5_stats(const u8* __restrict_
             sq_accum_px(A, gv, m[i], GATE && rp != nullptr, (GATE && rp) ? (int)rp[i] : 0, mp != nullptr, mp ? mp[i] : 0.f, mp ? vp[i] : 1.f, z_thresh);
         }
     }
-    sq_accum_finish(A, acc, zm, nanf_, n, mp != nullptr, out, nsq, decisions, want_hough, hough_work, hough_out, GATE ? dm : DetectMasks());
+    sq_accum_finish(A, acc, zm, nanf_, n, mp != nullptr, out, nsq, decisions, want_hough, hough_work, hough_out, descs[blockIdx.x].cnt,
+                    GATE ? dm : DetectMasks());
 }
 
 int launch_squares_pre5_stats(cbv_ctx* ctx, const u8* src, size_t src_frame_stride, const SquareDesc* descs, int n, u8* gray,
