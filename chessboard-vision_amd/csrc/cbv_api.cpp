@@ -1128,8 +1128,8 @@ extern "C" int cbv_squares_set_ref_mask(cbv_squares* s, uint64_t mask)
 {
     if (!s) return CBV_ERR_ARG;
     cbv_ctx* ctx = s->ctx;
-    if (s->n == 0) return cbv_fail(ctx, CBV_ERR_STATE, "cbv_squares_set_ref_mask: no squares loaded");
     CBV_ENTER(ctx);
+    if (s->n == 0) return cbv_fail(ctx, CBV_ERR_STATE, "cbv_squares_set_ref_mask: no squares loaded");
     RC(launch_squares_set_ref_mask(ctx, (const SquareDesc*)s->d_descs.p, s->n, (const u8*)s->d_gray.p, (u8*)s->d_ref.p, mask));
     s->has_ref = true;
     return CBV_OK; // asynchronous: later calls on this context are ordered behind it
@@ -1294,8 +1294,8 @@ extern "C" int cbv_squares_detect_changes(cbv_squares* s, const cbv_host_image* 
     if (!s) return CBV_ERR_ARG;
     cbv_ctx* ctx = s->ctx;
     if (!prm || !out) return cbv_fail(ctx, CBV_ERR_ARG, "cbv_squares_detect_changes: null argument");
-    if (!s->has_model) return cbv_fail(ctx, CBV_ERR_STATE, "cbv_squares_detect_changes: not calibrated");
     CBV_ENTER(ctx);
+    if (!s->has_model) return cbv_fail(ctx, CBV_ERR_STATE, "cbv_squares_detect_changes: not calibrated");
     RC(hough_params_check(ctx, &prm->hough));
     u8* hst;
     const size_t o_back = 8192, o_wk = 40960;
