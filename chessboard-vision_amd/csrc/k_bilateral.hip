@@ -246,7 +246,9 @@ __global__ __launch_bounds__(NT) void k_bilateral(const u8* __restrict__ src, u8
                 out.d[0] = out.d[1] = out.d[2] = 0;
 #pragma unroll
                 for (int o = 0; o < 4; o++) {
-                    const float inv = 1.f / sw[a][o];
+                    // the weight sum lies in [1, 49]: the centre tap's weight is exactly 1.0 (space 1 x colour 1) and no
+                    // weight exceeds 1, so the exact reciprocal of that interval applies
+                    const float inv = d_rcp_1_64(sw[a][o]);
                     // v_cvt_pk_u8_f32: cvRound (half to even) + pack; the value is a weighted mean of bytes, already in range
                     out.d[(3 * o) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(sb[a][o] * inv, (3 * o) & 3, out.d[(3 * o) >> 2]);
                     out.d[(3 * o + 1) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(sg[a][o] * inv, (3 * o + 1) & 3, out.d[(3 * o + 1) >> 2]);
