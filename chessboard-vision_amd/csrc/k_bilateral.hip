@@ -51,6 +51,7 @@ __global__ __launch_bounds__(NT) void k_bilateral(const u8* __restrict__ src, u8
                                                            const BilateralTabs* __restrict__ bt, TileSet ts, int batch,
                                                            SatGate gate)
 {
+    static_assert((2 * R + 1) * (2 * R + 1) < 128, "the epilogue's d_rcp_1_64 is verified for weight sums in [1, 128)");
     // static LDS (69 KB): compile-time addresses let the table gather use the ds_read immediate offset
 #ifdef BL_TWO_COPIES
     // experiment (profiles/r03/bilateral_two_copies.txt): a second copy of the table 16 banks further on, used by the odd
