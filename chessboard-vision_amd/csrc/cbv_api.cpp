@@ -934,8 +934,8 @@ extern "C" int cbv_squares_calibrate(cbv_squares* s, double initial_variance, co
 {
     if (!s) return CBV_ERR_ARG;
     cbv_ctx* ctx = s->ctx;
-    if (s->n == 0) return cbv_fail(ctx, CBV_ERR_STATE, "cbv_squares_calibrate: no squares loaded");
     CBV_ENTER(ctx);
+    if (s->n == 0) return cbv_fail(ctx, CBV_ERR_STATE, "cbv_squares_calibrate: no squares loaded");
     const u8* sel;
     RC(squares_select(s, select, &sel));
     RC(launch_squares_calibrate(ctx, (const SquareDesc*)s->d_descs.p, s->n, (const u8*)s->d_gray.p, (float*)s->d_mean.p, (float*)s->d_var.p,
@@ -949,8 +949,8 @@ extern "C" int cbv_squares_ema(cbv_squares* s, double alpha, const uint8_t* sele
 {
     if (!s) return CBV_ERR_ARG;
     cbv_ctx* ctx = s->ctx;
-    if (!s->has_model) return cbv_fail(ctx, CBV_ERR_STATE, "cbv_squares_ema: not calibrated");
     CBV_ENTER(ctx);
+    if (!s->has_model) return cbv_fail(ctx, CBV_ERR_STATE, "cbv_squares_ema: not calibrated");
     const u8* sel;
     RC(squares_select(s, select, &sel));
     RC(launch_squares_ema(ctx, (const SquareDesc*)s->d_descs.p, s->n, (const u8*)s->d_gray.p, (float*)s->d_mean.p, (float*)s->d_var.p, sq_sd(s), alpha, sel));
@@ -962,8 +962,8 @@ extern "C" int cbv_squares_set_ref(cbv_squares* s, const uint8_t* select)
 {
     if (!s) return CBV_ERR_ARG;
     cbv_ctx* ctx = s->ctx;
-    if (s->n == 0) return cbv_fail(ctx, CBV_ERR_STATE, "cbv_squares_set_ref: no squares loaded");
     CBV_ENTER(ctx);
+    if (s->n == 0) return cbv_fail(ctx, CBV_ERR_STATE, "cbv_squares_set_ref: no squares loaded");
     const u8* sel;
     RC(squares_select(s, select, &sel));
     RC(launch_squares_set_ref(ctx, (const SquareDesc*)s->d_descs.p, s->n, (const u8*)s->d_gray.p, (u8*)s->d_ref.p, sel));
@@ -976,9 +976,9 @@ extern "C" int cbv_squares_stats(cbv_squares* s, int use_ref, int use_model, dou
 {
     if (!s) return CBV_ERR_ARG;
     cbv_ctx* ctx = s->ctx;
+    CBV_ENTER(ctx);
     if (!out || s->n == 0) return cbv_fail(ctx, CBV_ERR_STATE, "cbv_squares_stats: no squares loaded or null output");
     if (use_model && !s->has_model) return cbv_fail(ctx, CBV_ERR_STATE, "cbv_squares_stats: model requested but not calibrated");
-    CBV_ENTER(ctx);
     RC(launch_squares_stats(ctx, (const SquareDesc*)s->d_descs.p, s->n, (const u8*)s->d_gray.p, 0, use_ref ? (const u8*)s->d_ref.p : nullptr,
                             use_model ? (const float*)s->d_mean.p : nullptr, use_model ? (const float*)sq_sd(s) : nullptr,
                             (const u8*)s->d_masks.p, (float)z_threshold, (cbv_sq_stats*)s->d_stats.p, 1));
@@ -1018,8 +1018,8 @@ extern "C" int cbv_squares_hough(cbv_squares* s, const cbv_hough_params* prm, cb
 {
     if (!s) return CBV_ERR_ARG;
     cbv_ctx* ctx = s->ctx;
-    if (!out || s->n == 0) return cbv_fail(ctx, CBV_ERR_STATE, "cbv_squares_hough: no squares loaded or null output");
     CBV_ENTER(ctx);
+    if (!out || s->n == 0) return cbv_fail(ctx, CBV_ERR_STATE, "cbv_squares_hough: no squares loaded or null output");
     HoughCfg hc;
     RC(hough_cfg(ctx, prm, s->descs, &hc));
     RC(dev_ensure(ctx, &s->d_hough, sizeof(cbv_hough_result) * CBV_MAX_SQUARES));
@@ -1217,6 +1217,9 @@ struct FastLayout {
 static int fast_layout(cbv_squares* s, FastLayout* L)
 {
     const size_t o_retry = 512, o_out = 1024;
+    // the block is copied back to offset 8192 of the 64 KB pinned staging area, whose tail (from 40960) holds the host-built worklist
+    static_assert(8192 + 64 + (2 * sizeof(cbv_sq_stats) + sizeof(cbv_hough_result)) * CBV_MAX_SQUARES <= 40960, "result block overruns the staging area");
+    static_assert(sizeof(SquareDesc) * CBV_MAX_SQUARES <= 8192 && 40960 + 4 * (1 + CBV_MAX_SQUARES) <= 65536, "staging layout");
     L->o_flags = 0;
     L->o_stats = 64;
     L->o_stats5 = L->o_stats + sizeof(cbv_sq_stats) * CBV_MAX_SQUARES;
@@ -1395,8 +1398,8 @@ extern "C" int cbv_squares_get(cbv_squares* s, int which, int index, void* out)
     cbv_ctx* ctx = s->ctx;
     void* p;
     size_t bytes;
-    RC(squares_plane(s, which, index, &p, &bytes));
     CBV_ENTER(ctx);
+    RC(squares_plane(s, which, index, &p, &bytes));
     CBV_HIP(ctx, hipMemcpyAsync(out, p, bytes, hipMemcpyDeviceToHost, ctx->stream));
     CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return CBV_OK;
@@ -1408,8 +1411,8 @@ extern "C" int cbv_squares_set(cbv_squares* s, int which, int index, const void*
     cbv_ctx* ctx = s->ctx;
     void* p;
     size_t bytes;
-    RC(squares_plane(s, which, index, &p, &bytes));
     CBV_ENTER(ctx);
+    RC(squares_plane(s, which, index, &p, &bytes));
     CBV_HIP(ctx, hipMemcpyAsync(p, in, bytes, hipMemcpyHostToDevice, ctx->stream));
     if (which == 3) RC(launch_squares_refresh_sd(ctx, (const SquareDesc*)s->d_descs.p, (const float*)s->d_var.p, sq_sd(s), index));
     CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1555,8 +1558,9 @@ extern "C" int cbv_pipeline_create(cbv_ctx* ctx, int w, int h, int max_frames, c
     p->g = tight_geom(w, h);
     hipError_t e = hipMalloc((void**)&p->frames, p->g.frame_stride * max_frames + 256);
     if (e != hipSuccess) {
+        const size_t want = p->g.frame_stride * max_frames;
         delete p;
-        return cbv_fail(ctx, CBV_ERR_HIP, "hipMalloc of %zu bytes for the frame ring failed: %s", p->g.frame_stride * max_frames, hipGetErrorString(e));
+        return cbv_fail(ctx, CBV_ERR_HIP, "hipMalloc of %zu bytes for the frame ring failed: %s", want, hipGetErrorString(e));
     }
     *out = p;
     return CBV_OK;
@@ -1858,6 +1862,66 @@ extern "C" int cbv_pipeline_synth(cbv_pipeline* p, int slot0, int count, const u
     return CBV_OK;
 }
 
+// second half of cbv_pipeline_run: join the lanes on the scan's stream, HoughCircles second pass, temporal scan, run record
+static int pipeline_run_tail(cbv_pipeline* p, cbv_pipeline::RunRec* rec, int slot0, int count, bool inline_scan, const bool* lane_used,
+                             hipStream_t main_stream)
+{
+    cbv_ctx* ctx = p->ctx;
+    const cbv_pipeline_config& cfg = p->cfg;
+    const int n = cfg.n_rois;
+    if (!p->scan_stream) {
+        RC(ctx_worker_stream(ctx, &ctx->scan_stream, &p->scan_stream));
+        CBV_HIP(ctx, hipEventCreateWithFlags(&p->main_done, hipEventDisableTiming));
+    }
+    hipStream_t scan_on = inline_scan ? main_stream : p->scan_stream;
+    if (!inline_scan) {
+        CBV_HIP(ctx, hipEventRecord(p->main_done, main_stream));
+        CBV_HIP(ctx, hipStreamWaitEvent(scan_on, p->main_done, 0));
+    }
+    // every forked lane is joined, in the inline case too (chunk = 1 puts the second frame of a two-frame run on lane 1)
+    for (int l = 1; l < p->n_lanes; l++)
+        if (lane_used[l]) {
+            CBV_HIP(ctx, hipEventRecord(p->lane_done[l], p->lane_stream[l]));
+            CBV_HIP(ctx, hipStreamWaitEvent(scan_on, p->lane_done[l], 0));
+        }
+    // every lane has read its frames: a later cbv_pipeline_submit may overwrite these slots after this event
+    CBV_HIP(ctx, hipEventRecord(rec->lanes_ev, scan_on));
+    ctx->stream = scan_on;
+    struct Restore {
+        cbv_ctx* c;
+        hipStream_t s;
+        ~Restore() { c->stream = s; }
+    } restore{ctx, main_stream};
+    if (cfg.use_hough) // squares whose first HoughCircles pass overflowed (normally none), before the scan reads the decisions
+        RC(launch_hough_second(ctx, (const SquareDesc*)p->d_descs.p, n, (const u8*)p->d_gray.p + p->plane_total * slot0, p->plane_total,
+                               p->hough_cfg, (cbv_hough_result*)p->d_hough.p + (size_t)CBV_MAX_SQUARES * slot0,
+                               (u8*)p->d_dec.p + (size_t)CBV_MAX_SQUARES * slot0, (const u32*)rec->retry.p, n * count));
+    ScanParams sp;
+    sp.n = n;
+    sp.history_size = cfg.history_size;
+    sp.min_presence = cfg.min_presence;
+    sp.change_threshold = cfg.change_threshold;
+    sp.with_model = p->calibrated ? 1 : 0;
+    sp.stable_table = 0;
+    for (int len = 1; len <= 7 && len <= cfg.history_size; len++)
+        for (int sum = 0; sum <= len; sum++)
+            if ((double)sum / (double)len >= cfg.min_presence) sp.stable_table |= 1ull << (len * 8 + sum);
+    sp.thr_is_int = (cfg.change_threshold == (double)(int)cfg.change_threshold && cfg.change_threshold >= 0 && cfg.change_threshold < 256) ? 1 : 0;
+    sp.thr_int = (int)cfg.change_threshold;
+    // + NoiseHandler on the frames' visual_changes sets (game_session.py:165)
+    RC(launch_scan(ctx, (const SquareDesc*)p->d_descs.p, sp, (const u8*)p->d_gray.p + p->plane_total * slot0, p->plane_total,
+                   (const u8*)p->d_dec.p + (size_t)CBV_MAX_SQUARES * slot0, (u8*)p->d_ref.p, (ScanState*)p->d_state.p,
+                   (u8*)p->d_flags.p + (size_t)CBV_MAX_SQUARES * slot0, (cbv_frame_result*)p->d_results.p + slot0, count,
+                   p->has_check ? (const u64*)p->d_check.p + slot0 : nullptr, (cbv_noise_state*)p->d_noise_state.p,
+                   (cbv_noise_result*)p->d_noise.p + slot0));
+    CBV_HIP(ctx, hipEventRecord(rec->scan_ev, scan_on));
+    rec->s0 = slot0;
+    rec->cnt = count;
+    rec->seq = ++p->run_seq;
+    rec->live = true;
+    return CBV_OK;
+}
+
 extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
 {
     if (!p || !p->configured) return CBV_ERR_STATE;
@@ -1952,65 +2016,19 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
                                   p->hough_cfg, hres, dec, work, b, (u32*)rec->retry.p, s0 - slot0);
     }
     ctx->stream = main_stream;
-    if (rc_all) {
-        // a launch failed after lanes were forked: whatever they already enqueued on these slots and scratch buffers must
-        // not outlive the call unordered (no RunRec goes live for a failed run)
+    // A failure after lanes were forked: whatever they already enqueued on these slots and scratch buffers must not outlive
+    // the call unordered (no RunRec goes live for a failed run), whether a lane's launch failed or the join / scan below did.
+    auto drain = [&](int rc) {
+        ctx->stream = main_stream;
         for (int l = 1; l < p->n_lanes; l++)
             if (lane_used[l]) (void)hipStreamSynchronize(p->lane_stream[l]);
+        if (p->scan_stream) (void)hipStreamSynchronize(p->scan_stream);
         (void)hipStreamSynchronize(main_stream);
-        return rc_all;
-    }
-    if (!p->scan_stream) {
-        RC(ctx_worker_stream(ctx, &ctx->scan_stream, &p->scan_stream));
-        CBV_HIP(ctx, hipEventCreateWithFlags(&p->main_done, hipEventDisableTiming));
-    }
-    hipStream_t scan_on = inline_scan ? main_stream : p->scan_stream;
-    if (!inline_scan) {
-        CBV_HIP(ctx, hipEventRecord(p->main_done, main_stream));
-        CBV_HIP(ctx, hipStreamWaitEvent(scan_on, p->main_done, 0));
-    }
-    // every forked lane is joined, in the inline case too (chunk = 1 puts the second frame of a two-frame run on lane 1)
-    for (int l = 1; l < p->n_lanes; l++)
-        if (lane_used[l]) {
-            CBV_HIP(ctx, hipEventRecord(p->lane_done[l], p->lane_stream[l]));
-            CBV_HIP(ctx, hipStreamWaitEvent(scan_on, p->lane_done[l], 0));
-        }
-    // every lane has read its frames: a later cbv_pipeline_submit may overwrite these slots after this event
-    CBV_HIP(ctx, hipEventRecord(rec->lanes_ev, scan_on));
-    ctx->stream = scan_on;
-    struct Restore {
-        cbv_ctx* c;
-        hipStream_t s;
-        ~Restore() { c->stream = s; }
-    } restore{ctx, main_stream};
-    if (cfg.use_hough) // squares whose first HoughCircles pass overflowed (normally none), before the scan reads the decisions
-        RC(launch_hough_second(ctx, (const SquareDesc*)p->d_descs.p, n, (const u8*)p->d_gray.p + p->plane_total * slot0, p->plane_total,
-                               p->hough_cfg, (cbv_hough_result*)p->d_hough.p + (size_t)CBV_MAX_SQUARES * slot0,
-                               (u8*)p->d_dec.p + (size_t)CBV_MAX_SQUARES * slot0, (const u32*)rec->retry.p, n * count));
-    ScanParams sp;
-    sp.n = n;
-    sp.history_size = cfg.history_size;
-    sp.min_presence = cfg.min_presence;
-    sp.change_threshold = cfg.change_threshold;
-    sp.with_model = p->calibrated ? 1 : 0;
-    sp.stable_table = 0;
-    for (int len = 1; len <= 7 && len <= cfg.history_size; len++)
-        for (int sum = 0; sum <= len; sum++)
-            if ((double)sum / (double)len >= cfg.min_presence) sp.stable_table |= 1ull << (len * 8 + sum);
-    sp.thr_is_int = (cfg.change_threshold == (double)(int)cfg.change_threshold && cfg.change_threshold >= 0 && cfg.change_threshold < 256) ? 1 : 0;
-    sp.thr_int = (int)cfg.change_threshold;
-    // + NoiseHandler on the frames' visual_changes sets (game_session.py:165)
-    RC(launch_scan(ctx, (const SquareDesc*)p->d_descs.p, sp, (const u8*)p->d_gray.p + p->plane_total * slot0, p->plane_total,
-                   (const u8*)p->d_dec.p + (size_t)CBV_MAX_SQUARES * slot0, (u8*)p->d_ref.p, (ScanState*)p->d_state.p,
-                   (u8*)p->d_flags.p + (size_t)CBV_MAX_SQUARES * slot0, (cbv_frame_result*)p->d_results.p + slot0, count,
-                   p->has_check ? (const u64*)p->d_check.p + slot0 : nullptr, (cbv_noise_state*)p->d_noise_state.p,
-                   (cbv_noise_result*)p->d_noise.p + slot0));
-    CBV_HIP(ctx, hipEventRecord(rec->scan_ev, scan_on));
-    rec->s0 = slot0;
-    rec->cnt = count;
-    rec->seq = ++p->run_seq;
-    rec->live = true;
-    return CBV_OK;
+        return rc;
+    };
+    if (rc_all) return drain(rc_all);
+    const int rc_tail = pipeline_run_tail(p, rec, slot0, count, inline_scan, lane_used, main_stream);
+    return rc_tail == CBV_OK ? CBV_OK : drain(rc_tail);
 }
 
 extern "C" int cbv_pipeline_set_check_squares(cbv_pipeline* p, int slot0, int count, const uint64_t* roi_masks)
