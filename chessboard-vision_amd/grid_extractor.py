@@ -60,6 +60,15 @@ class SquareDict(dict):
     """{(file, rank): view} as split_board returns it, plus `_parent` (the image) and `_layout` (SquareLayout)."""
     __slots__ = ("_parent", "_layout")
 
+    def __init__(self, *a, **k):
+        dict.__init__(self, *a, **k)
+        self._parent = None
+        self._layout = None
+
+    def __reduce__(self):
+        # copy / deepcopy / pickle give a plain dict: a copied view is no longer a view of the remembered image
+        return (dict, (dict(self),))
+
     def _detach(self):
         self._parent = None
         self._layout = None

@@ -118,6 +118,15 @@ def test_split_board_dict_carries_its_parent_until_mutated():
     plain = dict(sq)
     p3, lay3 = plan_of(plain)
     assert _is(p3, board) and lay3.rects == lay.rects
+    # copies are plain dicts (a deep-copied view is not a view of the remembered image any more), a bare SquareDict is inert
+    import copy
+    import pickle
+    for dup in (copy.copy(sq), copy.deepcopy(sq), pickle.loads(pickle.dumps(sq)), sq.copy()):
+        assert type(dup) is dict and list(dup.keys()) == list(sq.keys())
+    deep = copy.deepcopy(sq)
+    deep[(3, 3)][:] = 7
+    assert not (board == 7).all() and (plan_of(deep) is None or plan_of(deep)[0].data != board.ctypes.data)
+    assert plan_of(SquareDict()) is None and SquareDict(a=1)._parent is None
     # a board that is itself a view (a reshaped capture buffer, a crop of a larger frame): rectangles in the owner's rows
     buf = np.zeros(700 * 640 * 3 + 5, np.uint8)
     frame = buf[:700 * 640 * 3].reshape(700, 640, 3)
