@@ -34,6 +34,7 @@ int dev_ensure(cbv_ctx* ctx, DevBuf* b, size_t bytes)
         b->p = nullptr;
         b->cap = 0;
     }
+    b->tag = 0;
     // whole 2 MiB units for anything large: the driver can then map the buffer with large GPU pages
     size_t cap = bytes >= (256u << 10) ? (bytes + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1) : (bytes + 4095) & ~(size_t)4095;
     CBV_HIP(ctx, hipMalloc(&b->p, cap));
@@ -70,6 +71,7 @@ void dev_free(DevBuf* b)
     if (b->p) (void)hipFree(b->p);
     b->p = nullptr;
     b->cap = 0;
+    b->tag = 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -372,7 +374,17 @@ struct SmallLayout {
     u8* luts;
     u32* packed; // CLAHE corner words (k_clahe_lut -> k_clahe_apply), null when not reserved
     u8* norm_lut;
+    // The buffer's tag says which (tiles, batch) layout of `aux` is known to be as k_reset_aux leaves it: enhance_dev's own
+    // kernels restore that state as they go (launch_clahe_lut, self_clean), so a pass over the same layout needs no reset
+    // launch.  Everything else that writes `aux` leaves the tag 0 (aux_dirty).
+    DevBuf* owner;
 };
+static unsigned long long aux_clean_tag(int tiles, int batch) { return (1ull << 63) | ((unsigned long long)tiles << 32) | (unsigned)batch; }
+static int aux_reset(cbv_ctx* ctx, const SmallLayout& S, int tiles, int batch) // reset for a stand-alone stage
+{
+    S.owner->tag = 0;
+    return launch_reset_aux(ctx, S.aux, tiles, batch);
+}
 
 // tiles_x / tiles_y > 0 also reserve the packed CLAHE corner words ([batch][tiles_y + 1][tiles_x + 1][256] u32)
 static int small_layout(cbv_ctx* ctx, DevBuf* buf, int tiles, int batch, SmallLayout* L, int tiles_x = 0, int tiles_y = 0)
@@ -385,6 +397,7 @@ static int small_layout(cbv_ctx* ctx, DevBuf* buf, int tiles, int batch, SmallLa
     if (tiles_x <= 0 || tiles_y <= 0) pk_b = 0;
     int rc = dev_ensure(ctx, buf, aux_b + lut_b + nl_b + pk_b);
     if (rc) return rc;
+    L->owner = buf;
     L->aux = (u32*)buf->p;
     L->luts = (u8*)buf->p + aux_b;
     L->norm_lut = (u8*)buf->p + aux_b + lut_b;
@@ -406,6 +419,7 @@ extern "C" int cbv_apply_color_profile(cbv_ctx* ctx, const uint8_t* bgr, int w, 
     RC(dev_ensure(ctx, &ctx->a, g.frame_stride));
     SmallLayout S;
     RC(small_layout(ctx, &ctx->small, 1, 1, &S));
+    S.owner->tag = 0;
     ClaheGeom cg = clahe_geom(w, h, 0.0, 1, 1); // one tile = whole image; only used for the traversal
     RC(launch_color_lab_hist(ctx, (const u8*)ctx->in.p, (u8*)ctx->a.p, S.aux, g, cg, 1, 1, 0));
     return download(ctx, ctx->a.p, out, w * 3, h, out_stride);
@@ -425,7 +439,7 @@ extern "C" int cbv_correct_lighting(cbv_ctx* ctx, const uint8_t* bgr, int w, int
     int tiles = tiles_x * tiles_y;
     SmallLayout S;
     RC(small_layout(ctx, &ctx->small, tiles, 1, &S, tiles_x, tiles_y));
-    RC(launch_reset_aux(ctx, S.aux, tiles, 1));
+    RC(aux_reset(ctx, S, tiles, 1));
     RC(launch_color_lab_hist(ctx, (const u8*)ctx->in.p, (u8*)ctx->a.p, S.aux, g, cg, 1, 0, 1));
     RC(launch_clahe_lut(ctx, S.aux, S.luts, cg, 1, S.packed));
     RC(launch_clahe_apply(ctx, (const u8*)ctx->a.p, S.packed, (u8*)ctx->b.p, g, cg, 1));
@@ -443,6 +457,7 @@ extern "C" int cbv_clahe_apply(cbv_ctx* ctx, const uint8_t* gray, int w, int h, 
     ClaheGeom cg = clahe_geom(w, h, clip_limit, tiles_x, tiles_y);
     SmallLayout S;
     RC(small_layout(ctx, &ctx->small, tiles_x * tiles_y, 1, &S));
+    S.owner->tag = 0;
     RC(launch_clahe_gray(ctx, (const u8*)ctx->in.p, w, h, w, cg, S.aux, S.luts, (u8*)ctx->a.p));
     return download(ctx, ctx->a.p, out, w, h, out_stride);
 }
@@ -472,7 +487,7 @@ extern "C" int cbv_sharpen(cbv_ctx* ctx, const uint8_t* bgr, int w, int h, int s
     RC(dev_ensure(ctx, &ctx->a, g.frame_stride));
     SmallLayout S;
     RC(small_layout(ctx, &ctx->small, 1, 1, &S));
-    RC(launch_reset_aux(ctx, S.aux, 1, 1));
+    RC(aux_reset(ctx, S, 1, 1));
     RC(launch_sharpen(ctx, (const u8*)ctx->in.p, (u8*)ctx->a.p, S.aux, 1, g, kernel9, 1));
     return download(ctx, ctx->a.p, out, w * 3, h, out_stride);
 }
@@ -490,10 +505,9 @@ extern "C" int cbv_normalize_intensity(cbv_ctx* ctx, const uint8_t* bgr, int w, 
     RC(dev_ensure(ctx, &ctx->a, g.frame_stride));
     SmallLayout S;
     RC(small_layout(ctx, &ctx->small, 1, 1, &S));
-    RC(launch_reset_aux(ctx, S.aux, 1, 1));
+    RC(aux_reset(ctx, S, 1, 1));
     RC(launch_minmax(ctx, (const u8*)ctx->in.p, S.aux, 1, g, 1));
-    RC(launch_norm_lut(ctx, S.aux, 1, S.norm_lut, 1));
-    RC(launch_normalize(ctx, (const u8*)ctx->in.p, (u8*)ctx->a.p, S.norm_lut, g, 1));
+    RC(launch_normalize(ctx, (const u8*)ctx->in.p, (u8*)ctx->a.p, norm_from_minmax(S.aux, 1), g, 1));
     return download(ctx, ctx->a.p, out, w * 3, h, out_stride);
 }
 
@@ -512,7 +526,7 @@ extern "C" int cbv_prepare_analysis(cbv_ctx* ctx, const uint8_t* bgr, int w, int
     u8* dbin = dblur + plane;
     SmallLayout S;
     RC(small_layout(ctx, &ctx->small, 1, 1, &S));
-    RC(launch_reset_aux(ctx, S.aux, 1, 1));
+    RC(aux_reset(ctx, S, 1, 1));
     RC(launch_gray_blur_hist(ctx, (const u8*)ctx->in.p, dgray, dblur, S.aux, 1, g, 1));
     RC(launch_otsu(ctx, S.aux, 1, w * h, 1));
     RC(launch_threshold(ctx, dblur, dbin, S.aux, 1, w, h, 1));
@@ -602,15 +616,28 @@ static PxRect px_dilate(PxRect r, int d, Geom g)
 
 // `region` (with a third buffer C, and only when the caller folds normalize into its own gather): the consumer samples
 // just these pixels of the enhanced frame; see "Region-limited enhancement" in cbv_internal.h.
+// `norm`: where the consumer of a fold_norm result finds cv2.normalize's byte map (NormSrc).
 static int enhance_dev(cbv_ctx* ctx, const u8* src, u8* A, u8* B, Geom g, const cbv_enhance_params* P, SmallLayout S,
-                       int batch, bool fold_norm, u8** result, const PxRect* region = nullptr, u8* C = nullptr)
+                       int batch, bool fold_norm, u8** result, NormSrc* norm, const PxRect* region = nullptr, u8* C = nullptr)
 {
     ClaheGeom cg = clahe_geom(g.w, g.h, P->clahe_clip_limit, P->tiles_x, P->tiles_y);
     int tiles = P->tiles_x * P->tiles_y;
-    RC(launch_reset_aux(ctx, S.aux, tiles, batch));
-    RC(launch_color_lab_hist(ctx, src, A, S.aux, g, cg, batch, P->profile.enabled ? 1 : 0, 1));
     if (!S.packed) return cbv_fail(ctx, CBV_ERR_STATE, "enhance_dev: the small-buffer layout lacks the packed CLAHE words");
-    RC(launch_clahe_lut(ctx, S.aux, S.luts, cg, batch, S.packed));
+    // histograms zero, [min, max] = [255, 0]: by a launch the first time this layout of the buffer is used, by the previous
+    // pass's k_clahe_lut afterwards (SmallLayout::owner).  The tag stays 0 until every launch of this pass is enqueued.
+    const unsigned long long clean = aux_clean_tag(tiles, batch);
+    if (S.owner->tag != clean) RC(launch_reset_aux(ctx, S.aux, tiles, batch));
+    S.owner->tag = 0;
+    struct MarkClean {
+        DevBuf* b;
+        unsigned long long tag;
+        bool ok = false;
+        ~MarkClean() { if (ok) b->tag = tag; }
+    } mark{S.owner, clean};
+    RC(launch_color_lab_hist(ctx, src, A, S.aux, g, cg, batch, P->profile.enabled ? 1 : 0, 1));
+    RC(launch_clahe_lut(ctx, S.aux, S.luts, cg, batch, S.packed, 1));
+    // a run of a frame or two is launch latency: its consumer works the byte map out of [min, max] itself (NormSrc)
+    const bool lut_launch = batch > 2;
     if (region && C && fold_norm && sharpen_region_ok(P->sharpen_kernel) && region->x1 > region->x0 && region->y1 > region->y0) {
         // what each stage must find complete in its input: the stage after it, rounded out to that stage's tiles, plus
         // that stage's halo (sharpen 1 px, bilateral 4 px as staged)
@@ -629,20 +656,25 @@ static int enhance_dev(cbv_ctx* ctx, const u8* src, u8* A, u8* B, Geom g, const 
         RC(launch_clahe_apply(ctx, A, S.packed, B, g, cg, batch, &ec));
         RC(launch_bilateral(ctx, B, A, g, batch, &eb));
         RC(launch_sharpen(ctx, A, C, S.aux, tiles, g, P->sharpen_kernel, batch, &es));
-        RC(launch_norm_lut(ctx, S.aux, tiles, S.norm_lut, batch));
+        if (lut_launch) RC(launch_norm_lut(ctx, S.aux, tiles, S.norm_lut, batch));
+        *norm = lut_launch ? norm_from_lut(S.norm_lut) : norm_from_minmax(S.aux, tiles);
         *result = C;
+        mark.ok = true;
         return CBV_OK;
     }
     RC(launch_clahe_apply(ctx, A, S.packed, B, g, cg, batch));
     RC(launch_bilateral(ctx, B, A, g, batch));
     RC(launch_sharpen(ctx, A, B, S.aux, tiles, g, P->sharpen_kernel, batch));
-    RC(launch_norm_lut(ctx, S.aux, tiles, S.norm_lut, batch));
+    if (lut_launch) RC(launch_norm_lut(ctx, S.aux, tiles, S.norm_lut, batch));
+    *norm = lut_launch ? norm_from_lut(S.norm_lut) : norm_from_minmax(S.aux, tiles);
     if (fold_norm) {
         *result = B;
+        mark.ok = true;
         return CBV_OK;
     }
-    RC(launch_normalize(ctx, B, A, S.norm_lut, g, batch));
+    RC(launch_normalize(ctx, B, A, *norm, g, batch));
     *result = A;
+    mark.ok = true;
     return CBV_OK;
 }
 
@@ -697,7 +729,8 @@ extern "C" int cbv_process_pipeline(cbv_ctx* ctx, const uint8_t* bgr, int w, int
     SmallLayout S;
     RC(small_layout(ctx, &ctx->small, params->tiles_x * params->tiles_y, 1, &S, params->tiles_x, params->tiles_y));
     u8* res = nullptr;
-    RC(enhance_dev(ctx, (const u8*)ctx->in.p, (u8*)ctx->a.p, (u8*)ctx->b.p, g, params, S, 1, false, &res));
+    NormSrc norm;
+    RC(enhance_dev(ctx, (const u8*)ctx->in.p, (u8*)ctx->a.p, (u8*)ctx->b.p, g, params, S, 1, false, &res, &norm));
     return download(ctx, res, out, w * 3, h, out_stride);
 }
 
@@ -727,7 +760,7 @@ extern "C" int cbv_warp_perspective(cbv_ctx* ctx, const uint8_t* bgr, int w, int
     const double t1 = tm ? now() : 0;
     Geom g = tight_geom(w, h);
     RC(dev_ensure(ctx, &ctx->a, (size_t)dw * dh * 3 + 256));
-    RC(launch_warp(ctx, (const u8*)ctx->in.p, g, Minv, dw, dh, rot180, (u8*)ctx->a.p, dw * 3, (size_t)dw * dh * 3, nullptr, 1));
+    RC(launch_warp(ctx, (const u8*)ctx->in.p, g, Minv, dw, dh, rot180, (u8*)ctx->a.p, dw * 3, (size_t)dw * dh * 3, NormSrc(), 1));
     const double t2 = tm ? now() : 0;
     RC(rows_d2h(ctx, out, out_stride, ctx->a.p, dw * 3, dh));
     const double t3 = tm ? now() : 0;
@@ -1465,7 +1498,8 @@ struct cbv_pipeline {
     size_t plane_total = 0;
     // ingest: pinned host mirror of the frame ring, filled by the capture side and copied on its own stream
     u8* host_ring = nullptr;
-    u8* h_stage = nullptr; // pinned: results travel device -> here -> the caller's (pageable) buffer, two async copies and ONE wait
+    u8* h_stage = nullptr; // pinned mirror of d_results ([max_frames] records, then the HoughCircles overflow word): written by
+                           // every run's last kernel (ResultMirror), read by cbv_pipeline_results after a wait
     size_t h_stage_bytes = 0;
     hipStream_t copy_stream = nullptr;
     struct CopyRec {
@@ -1489,6 +1523,8 @@ struct cbv_pipeline {
         unsigned long long seq;
         hipEvent_t lanes_ev, scan_ev;
         bool live;
+        bool one_event; // a run of a frame or two, all on the caller's stream: only scan_ev is recorded (an event between two
+                        // kernels is a ~5 us bubble in a 150 us chain), and it stands for lanes_ev too
         DevBuf retry; // HoughCircles second-pass list of this run (HoughCfg::retry), frames numbered from the run's slot0
     };
     std::vector<RunRec> runs;
@@ -1498,6 +1534,9 @@ struct cbv_pipeline {
     int max_px = 0; // pixels of the largest square
     bool keep_enhanced = false;
 };
+
+// the HoughCircles overflow word of the pinned result mirror (behind its max_frames records)
+static u32* pipeline_over_word(cbv_pipeline* p) { return (u32*)(p->h_stage + ((sizeof(cbv_frame_result) * (size_t)p->max_frames + 7) & ~(size_t)7)); }
 
 static bool ranges_overlap(int a0, int an, int b0, int bn) { return a0 < b0 + bn && b0 < a0 + an; }
 
@@ -1699,6 +1738,17 @@ extern "C" int cbv_pipeline_configure(cbv_pipeline* p, const cbv_pipeline_config
     p->calibrated = false;
     RC(dev_ensure(ctx, &p->d_state, sizeof(ScanState) * n));
     RC(dev_ensure(ctx, &p->d_results, sizeof(cbv_frame_result) * p->max_frames));
+    {
+        const size_t want = sizeof(cbv_frame_result) * (size_t)p->max_frames + 16;
+        if (p->h_stage_bytes < want) {
+            if (p->h_stage) (void)hipHostFree(p->h_stage);
+            p->h_stage = nullptr;
+            p->h_stage_bytes = 0;
+            CBV_HIP(ctx, hipHostMalloc((void**)&p->h_stage, want, hipHostMallocDefault));
+            p->h_stage_bytes = want;
+        }
+        memset(p->h_stage, 0, p->h_stage_bytes);
+    }
     RC(dev_ensure(ctx, &p->d_flags, (size_t)CBV_MAX_SQUARES * p->max_frames));
     RC(dev_ensure(ctx, &p->d_dec, (size_t)CBV_MAX_SQUARES * p->max_frames));
     if (cfg->use_hough) {
@@ -1736,7 +1786,11 @@ extern "C" int cbv_pipeline_reset_state(cbv_pipeline* p)
     RC(join_scan(p)); // lanes and scan of the last run
     CBV_HIP(ctx, hipMemsetAsync(p->d_state.p, 0, sizeof(ScanState) * p->cfg.n_rois, ctx->stream));
     CBV_HIP(ctx, hipMemsetAsync(p->d_noise_state.p, 0, sizeof(cbv_noise_state), ctx->stream));
-    if (p->d_hough_over.p) CBV_HIP(ctx, hipMemsetAsync(p->d_hough_over.p, 0, 4, ctx->stream));
+    if (p->d_hough_over.p) {
+        CBV_HIP(ctx, hipMemsetAsync(p->d_hough_over.p, 0, 4, ctx->stream));
+        CBV_HIP(ctx, hipStreamSynchronize(ctx->stream)); // the runs that could still write the mirror's copy are behind us
+        *pipeline_over_word(p) = 0;
+    }
     return CBV_OK;
 }
 
@@ -1806,7 +1860,7 @@ extern "C" int cbv_pipeline_submit(cbv_pipeline* p, int slot0, int count)
         cbv_pipeline::RunRec* best = nullptr;
         for (auto& r : p->runs)
             if (r.live && ranges_overlap(slot0, count, r.s0, r.cnt) && (!best || r.seq > best->seq)) best = &r;
-        if (best) CBV_HIP(ctx, hipStreamWaitEvent(p->copy_stream, best->lanes_ev, 0));
+        if (best) CBV_HIP(ctx, hipStreamWaitEvent(p->copy_stream, best->one_event ? best->scan_ev : best->lanes_ev, 0));
     }
     CBV_HIP(ctx, hipMemcpyAsync(p->frames + p->g.frame_stride * slot0, p->host_ring + p->g.frame_stride * slot0,
                                 p->g.frame_stride * count, hipMemcpyHostToDevice, p->copy_stream));
@@ -1885,7 +1939,8 @@ static int pipeline_run_tail(cbv_pipeline* p, cbv_pipeline::RunRec* rec, int slo
             CBV_HIP(ctx, hipStreamWaitEvent(scan_on, p->lane_done[l], 0));
         }
     // every lane has read its frames: a later cbv_pipeline_submit may overwrite these slots after this event
-    CBV_HIP(ctx, hipEventRecord(rec->lanes_ev, scan_on));
+    rec->one_event = inline_scan;
+    if (!inline_scan) CBV_HIP(ctx, hipEventRecord(rec->lanes_ev, scan_on));
     ctx->stream = scan_on;
     struct Restore {
         cbv_ctx* c;
@@ -1908,12 +1963,16 @@ static int pipeline_run_tail(cbv_pipeline* p, cbv_pipeline::RunRec* rec, int slo
             if ((double)sum / (double)len >= cfg.min_presence) sp.stable_table |= 1ull << (len * 8 + sum);
     sp.thr_is_int = (cfg.change_threshold == (double)(int)cfg.change_threshold && cfg.change_threshold >= 0 && cfg.change_threshold < 256) ? 1 : 0;
     sp.thr_int = (int)cfg.change_threshold;
+    ResultMirror mir;
+    mir.records = (cbv_frame_result*)p->h_stage + slot0;
+    mir.over_src = cfg.use_hough ? (const u32*)p->d_hough_over.p : nullptr;
+    mir.over_dst = pipeline_over_word(p);
     // + NoiseHandler on the frames' visual_changes sets (game_session.py:165)
     RC(launch_scan(ctx, (const SquareDesc*)p->d_descs.p, sp, (const u8*)p->d_gray.p + p->plane_total * slot0, p->plane_total,
                    (const u8*)p->d_dec.p + (size_t)CBV_MAX_SQUARES * slot0, (u8*)p->d_ref.p, (ScanState*)p->d_state.p,
                    (u8*)p->d_flags.p + (size_t)CBV_MAX_SQUARES * slot0, (cbv_frame_result*)p->d_results.p + slot0, count,
                    p->has_check ? (const u64*)p->d_check.p + slot0 : nullptr, (cbv_noise_state*)p->d_noise_state.p,
-                   (cbv_noise_result*)p->d_noise.p + slot0));
+                   (cbv_noise_result*)p->d_noise.p + slot0, mir));
     CBV_HIP(ctx, hipEventRecord(rec->scan_ev, scan_on));
     rec->s0 = slot0;
     rec->cnt = count;
@@ -1956,15 +2015,18 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
             break;
         }
     if (!rec) {
-        cbv_pipeline::RunRec r{0, 0, 0, nullptr, nullptr, false, DevBuf()};
+        cbv_pipeline::RunRec r{0, 0, 0, nullptr, nullptr, false, false, DevBuf()};
         CBV_HIP(ctx, hipEventCreateWithFlags(&r.lanes_ev, hipEventDisableTiming));
         CBV_HIP(ctx, hipEventCreateWithFlags(&r.scan_ev, hipEventDisableTiming));
         p->runs.push_back(r);
         rec = &p->runs.back();
     }
+    // the second-pass list's counter: zeroed before the lanes fork from this stream, or, when the run is ONE chunk, by that
+    // chunk's k_warp (a memset is a launch of its own, ~13 us with its bubble in front of a 150 us chain)
+    const bool retry_zero_in_warp = chunks == 1;
     if (cfg.use_hough) {
         RC(dev_ensure(ctx, &rec->retry, sizeof(u32) * (1 + (size_t)CBV_MAX_SQUARES * p->max_frames)));
-        CBV_HIP(ctx, hipMemsetAsync(rec->retry.p, 0, sizeof(u32), main_stream)); // before the lanes fork from this stream
+        if (!retry_zero_in_warp) CBV_HIP(ctx, hipMemsetAsync(rec->retry.p, 0, sizeof(u32), main_stream));
     }
     for (auto& c : p->copies) // ingest copies of these slots must have landed
         if (c.pending && ranges_overlap(slot0, count, c.s0, c.cnt)) {
@@ -1988,19 +2050,21 @@ extern "C" int cbv_pipeline_run(cbv_pipeline* p, int slot0, int count)
         const int b = std::min(p->chunk, slot0 + count - s0);
         const u8* src = p->frames + p->g.frame_stride * s0;
         u8* res = nullptr;
-        rc_all = enhance_dev(ctx, src, p->A[lane], p->B[lane], p->g, &cfg.enhance, SL, b, !p->keep_enhanced, &res,
+        NormSrc norm;
+        rc_all = enhance_dev(ctx, src, p->A[lane], p->B[lane], p->g, &cfg.enhance, SL, b, !p->keep_enhanced, &res, &norm,
                              p->use_region ? &p->region : nullptr, p->C[lane]);
         if (rc_all) break;
         u8* wdst = p->warped + p->warped_stride * s0;
         u32* work = cfg.use_hough ? (u32*)p->lane_work[lane].p : nullptr; // worklist counter: zeroed by k_warp
+        u32* retry0 = cfg.use_hough && retry_zero_in_warp ? (u32*)rec->retry.p : nullptr;
         if (p->keep_enhanced) {
             if (hipMemcpyAsync(p->enhanced + p->g.frame_stride * s0, res, p->g.frame_stride * b, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
                 rc_all = cbv_fail(ctx, CBV_ERR_HIP, "copy of the enhanced frames failed");
                 break;
             }
-            rc_all = launch_warp(ctx, res, p->g, p->Minv, S, S, cfg.rot180, wdst, S * 3, p->warped_stride, nullptr, b, work);
+            rc_all = launch_warp(ctx, res, p->g, p->Minv, S, S, cfg.rot180, wdst, S * 3, p->warped_stride, NormSrc(), b, work, retry0);
         } else {
-            rc_all = launch_warp(ctx, res, p->g, p->Minv, S, S, cfg.rot180, wdst, S * 3, p->warped_stride, SL.norm_lut, b, work);
+            rc_all = launch_warp(ctx, res, p->g, p->Minv, S, S, cfg.rot180, wdst, S * 3, p->warped_stride, norm, b, work, retry0);
         }
         if (rc_all) break;
         u8* dec = (u8*)p->d_dec.p + (size_t)CBV_MAX_SQUARES * s0;
@@ -2051,33 +2115,19 @@ extern "C" int cbv_pipeline_results(cbv_pipeline* p, int slot0, int count, cbv_f
     cbv_ctx* ctx = p->ctx;
     CBV_ENTER(ctx);
     RC(join_scan(p)); // lanes and scan of the last run
-    // through a pinned staging buffer: a copy into the caller's pageable memory is staged by the runtime anyway, one
-    // blocking copy at a time (two of them cost ~45 us per call, a fifth of a single-frame run)
+    if (!p->configured || !p->h_stage) return cbv_fail(ctx, CBV_ERR_STATE, "cbv_pipeline_results: the pipeline is not configured");
+    // the records are already in pinned host memory (ResultMirror): wait for the runs, copy on the host
     const size_t bytes = sizeof(cbv_frame_result) * (size_t)count;
-    if (p->h_stage_bytes < bytes + 16) {
-        if (p->h_stage) (void)hipHostFree(p->h_stage);
-        p->h_stage = nullptr;
-        p->h_stage_bytes = 0;
-        const size_t want = sizeof(cbv_frame_result) * (size_t)p->max_frames + 16;
-        if (hipHostMalloc((void**)&p->h_stage, want, hipHostMallocDefault) != hipSuccess) {
-            p->h_stage = nullptr;
-            return cbv_fail(ctx, CBV_ERR_HIP, "pinned staging buffer for results (%zu bytes) failed", want);
-        }
-        p->h_stage_bytes = want;
-    }
-    u32* over_h = (u32*)(p->h_stage + ((bytes + 7) & ~(size_t)7));
-    *over_h = 0;
-    CBV_HIP(ctx, hipMemcpyAsync(p->h_stage, (cbv_frame_result*)p->d_results.p + slot0, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    if (p->configured && p->cfg.use_hough && p->d_hough_over.p)
-        CBV_HIP(ctx, hipMemcpyAsync(over_h, p->d_hough_over.p, 4, hipMemcpyDeviceToHost, ctx->stream));
     CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    memcpy(out, p->h_stage, bytes);
+    memcpy(out, (const cbv_frame_result*)p->h_stage + slot0, bytes);
+    u32* over_h = pipeline_over_word(p);
     const u32 over = *over_h;
     if (over) {
         // A truncated candidate list may change has_piece: never hand that over as if it were HoughCircles' answer.  The
         // counter is cleared on read, so the error is reported ONCE, by the first results call after the runs it
         // happened in, and later frames are not poisoned; `out` is filled and valid except for the flagged squares.
         CBV_HIP(ctx, hipMemsetAsync(p->d_hough_over.p, 0, 4, ctx->stream));
+        *over_h = 0; // (nothing is in flight: the next run's last kernel writes the word again)
         return cbv_fail(ctx, CBV_ERR_UNSUPPORTED, "HoughCircles: the candidate list overflowed even the second pass on %u square(s) since the "
                         "previous cbv_pipeline_results; those occupancy bits are not HoughCircles' (cbv_pipeline_hough flags name the squares)", over);
     }

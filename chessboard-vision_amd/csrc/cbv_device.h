@@ -33,6 +33,16 @@ __device__ __forceinline__ float d_rcp_1_64(float x)
     return __fmaf_rn(__fmaf_rn(-x, y, 1.0f), y, y);
 }
 
+// cv2.normalize(NORM_MINMAX, 0, 255) as a byte map: entry t for a frame whose bytes span [vmin, vmax]: scale and shift in
+// double, one float fma per value (cvt_32f), round half to even, saturate
+__device__ __forceinline__ u8 d_norm_lut_entry(int vmin, int vmax, int t)
+{
+    const double smin = (double)vmin, smax = (double)vmax;
+    const double scale = 255.0 * (smax - smin > 2.2204460492503131e-16 ? 1. / (smax - smin) : 0.);
+    const double shift = 0.0 - smin * scale;
+    return d_sat8_f(__fmaf_rn((float)t, (float)scale, (float)shift));
+}
+
 // cv::borderInterpolate(p, len, BORDER_REFLECT_101)
 __device__ __forceinline__ int d_reflect101(int p, int len)
 {

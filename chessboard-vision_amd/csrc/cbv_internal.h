@@ -77,6 +77,7 @@ int host_invert3x3(const double* S, double* D);
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    unsigned long long tag = 0; // what the owner knows about the contents; 0 after every (re)allocation
 };
 
 struct ProfSlot {
@@ -283,7 +284,9 @@ __host__ __device__ static inline size_t aux_words(int tiles) { return (size_t)t
 int launch_reset_aux(cbv_ctx* ctx, u32* aux, int tiles, int batch);
 int launch_color_lab_hist(cbv_ctx* ctx, const u8* src, u8* lab, u32* aux, Geom g, ClaheGeom cg, int batch,
                           int do_profile, int do_lab);
-int launch_clahe_lut(cbv_ctx* ctx, const u32* aux, u8* luts, ClaheGeom cg, int batch, u32* packed);
+// self_clean: the histograms are zeroed once read and [min, max] set to 255, 0, i.e. the kernel leaves the frame's words as
+// k_reset_aux would, for the NEXT pass over the same buffer (k_sharpen's min / max come later in this pass)
+int launch_clahe_lut(cbv_ctx* ctx, u32* aux, u8* luts, ClaheGeom cg, int batch, u32* packed, int self_clean = 0);
 int launch_clahe_apply(cbv_ctx* ctx, const u8* lab, const u32* packed, u8* dst, Geom g, ClaheGeom cg, int batch, const EnhanceRegion* er = nullptr);
 int launch_clahe_gray(cbv_ctx* ctx, const u8* src, int w, int h, int stride, ClaheGeom cg, u32* aux, u8* luts, u8* dst);
 int launch_bilateral(cbv_ctx* ctx, const u8* src, u8* dst, Geom g, int batch, const EnhanceRegion* er = nullptr);
@@ -295,9 +298,30 @@ PxRect sharpen_region_cover(Geom g, PxRect need);
 PxRect bilateral_region_cover(cbv_ctx* ctx, Geom g, int batch, PxRect need);
 PxRect clahe_region_cover(Geom g, PxRect need);
 int launch_norm_lut(cbv_ctx* ctx, const u32* aux, int tiles, u8* norm_lut, int batch);
-int launch_normalize(cbv_ctx* ctx, const u8* src, u8* dst, const u8* norm_lut, Geom g, int batch);
+// Where a kernel takes cv2.normalize's byte map from: a table k_norm_lut built ([frame][256]), or the frames' [min, max]
+// words themselves (`minmax` = frame 0's, `mm_stride` words apart), from which every workgroup works out the table it needs:
+// a launch of a frame or two is launch latency, and that way the chain has one launch fewer.  Neither: no mapping.
+struct NormSrc {
+    const u8* lut = nullptr;
+    const u32* minmax = nullptr;
+    size_t mm_stride = 0;
+};
+static inline NormSrc norm_from_lut(const u8* lut)
+{
+    NormSrc n;
+    n.lut = lut;
+    return n;
+}
+static inline NormSrc norm_from_minmax(const u32* aux, int tiles)
+{
+    NormSrc n;
+    n.minmax = aux + (size_t)tiles * 256;
+    n.mm_stride = aux_words(tiles);
+    return n;
+}
+int launch_normalize(cbv_ctx* ctx, const u8* src, u8* dst, NormSrc norm, Geom g, int batch);
 int launch_warp(cbv_ctx* ctx, const u8* src, Geom g, const double* Minv9, int dw, int dh, int rot180, u8* dst,
-                int dst_stride, size_t dst_frame_stride, const u8* norm_lut, int batch, u32* zero_word = nullptr);
+                int dst_stride, size_t dst_frame_stride, NormSrc norm, int batch, u32* zero_word = nullptr, u32* zero_word2 = nullptr);
 int launch_gray_blur_hist(cbv_ctx* ctx, const u8* src, u8* gray, u8* blur, u32* aux, int tiles, Geom g, int batch);
 int launch_otsu(cbv_ctx* ctx, u32* aux, int tiles, int total, int batch);
 int launch_threshold(cbv_ctx* ctx, const u8* blur, u8* binary, const u32* aux, int tiles, int w, int h, int batch);
@@ -398,6 +422,15 @@ struct ScanState {       // per square, device resident
 };
 int launch_scan_update_refs(cbv_ctx* ctx, const SquareDesc* descs, int n, const u8* gray, u8* ref, ScanState* state);
 int launch_noise(cbv_ctx* ctx, const u64* changes, size_t stride_words, int count, cbv_noise_state* state, cbv_noise_result* out);
+// Pinned host copy of a run's result records (`records` = the run's first slot there) and of HoughCircles' overflow
+// counter, written by the run's last kernel beside the device copy: cbv_pipeline_results then waits and copies on the
+// host instead of launching two device-to-host copies (~15 us of a 160 us frame).  All null: no mirror.
+struct ResultMirror {
+    cbv_frame_result* records = nullptr;
+    const u32* over_src = nullptr;
+    u32* over_dst = nullptr;
+};
 int launch_scan(cbv_ctx* ctx, const SquareDesc* descs, ScanParams sp, const u8* gray, size_t gray_frame_stride,
                 const u8* decisions, u8* ref, ScanState* state, u8* flags, cbv_frame_result* results, int count,
-                const u64* check = nullptr, cbv_noise_state* noise_state = nullptr, cbv_noise_result* noise_out = nullptr);
+                const u64* check = nullptr, cbv_noise_state* noise_state = nullptr, cbv_noise_result* noise_out = nullptr,
+                ResultMirror mir = ResultMirror());

@@ -237,14 +237,20 @@ int launch_color_lab_hist(cbv_ctx* ctx, const u8* src, u8* lab, u32* aux, Geom g
 // 3 = (ty2, tx2), where band b has ty1 = clamp(b - 1), ty2 = clamp(b) and pair p has tx1 = clamp(p - 1),
 // tx2 = clamp(p).  A tile writes its byte into every word it is a corner of (one to nine of them), so the apply
 // kernel does ONE gather per pixel instead of four.
-__global__ __launch_bounds__(256) void k_clahe_lut(const u32* __restrict__ aux, u8* __restrict__ luts, ClaheGeom cg,
-                                                    int tiles_total, u8* __restrict__ packed)
+__global__ __launch_bounds__(256) void k_clahe_lut(u32* __restrict__ aux, u8* __restrict__ luts, ClaheGeom cg,
+                                                    int tiles_total, u8* __restrict__ packed, int self_clean)
 {
     __shared__ int red[4];
     __shared__ int scan[256];
     const int tile = blockIdx.x, t = threadIdx.x;
-    const u32* hist = aux + (size_t)blockIdx.y * aux_words(tiles_total) + (size_t)tile * 256;
+    u32* hist = aux + (size_t)blockIdx.y * aux_words(tiles_total) + (size_t)tile * 256;
     int hv = (int)hist[t];
+    if (self_clean) {
+        // this kernel is the histograms' only reader, and the frame's [min, max] words are written later in the pass
+        // (k_sharpen) and read after that: leaving both as k_reset_aux would spares the next pass that launch
+        hist[t] = 0u;
+        if (tile == 0 && t < 2) aux[(size_t)blockIdx.y * aux_words(tiles_total) + (size_t)tiles_total * 256 + t] = t == 0 ? 255u : 0u;
+    }
     if (cg.clip > 0) {
         int excess = hv > cg.clip ? hv - cg.clip : 0;
         hv = min(hv, cg.clip);
@@ -292,11 +298,11 @@ __global__ __launch_bounds__(256) void k_clahe_lut(const u32* __restrict__ aux, 
     }
 }
 
-int launch_clahe_lut(cbv_ctx* ctx, const u32* aux, u8* luts, ClaheGeom cg, int batch, u32* packed)
+int launch_clahe_lut(cbv_ctx* ctx, u32* aux, u8* luts, ClaheGeom cg, int batch, u32* packed, int self_clean)
 {
     int tiles = cg.tiles_x * cg.tiles_y;
     prof_begin(ctx, CBV_K_CLAHE_LUT);
-    hipLaunchKernelGGL(k_clahe_lut, dim3(tiles, batch), dim3(256), 0, ctx->stream, aux, luts, cg, tiles, (u8*)packed);
+    hipLaunchKernelGGL(k_clahe_lut, dim3(tiles, batch), dim3(256), 0, ctx->stream, aux, luts, cg, tiles, (u8*)packed, self_clean);
     prof_end(ctx, CBV_K_CLAHE_LUT);
     CBV_HIP(ctx, hipGetLastError());
     return CBV_OK;
@@ -1054,12 +1060,7 @@ int launch_sharpen(cbv_ctx* ctx, const u8* src, u8* dst, u32* aux, int tiles, Ge
 __global__ void k_norm_lut(const u32* __restrict__ aux, int tiles_total, u8* __restrict__ norm_lut)
 {
     const u32* mm = aux + (size_t)blockIdx.x * aux_words(tiles_total) + (size_t)tiles_total * 256;
-    double smin = (double)(int)mm[0], smax = (double)(int)mm[1];
-    double scale = 255.0 * (smax - smin > 2.2204460492503131e-16 ? 1. / (smax - smin) : 0.);
-    double shift = 0.0 - smin * scale;
-    float a = (float)scale, b = (float)shift;
-    const float t = __fmaf_rn((float)(int)threadIdx.x, a, b); // cvt_32f: v_fma(src, scale, shift)
-    norm_lut[(size_t)blockIdx.x * 256 + threadIdx.x] = d_sat8_f(t);
+    norm_lut[(size_t)blockIdx.x * 256 + threadIdx.x] = d_norm_lut_entry((int)mm[0], (int)mm[1], (int)threadIdx.x);
 }
 
 int launch_norm_lut(cbv_ctx* ctx, const u32* aux, int tiles, u8* norm_lut, int batch)
@@ -1073,10 +1074,14 @@ int launch_norm_lut(cbv_ctx* ctx, const u32* aux, int tiles, u8* norm_lut, int b
 
 // rows are mapped 16 bytes per lane
 __global__ __launch_bounds__(256) void k_normalize(const u8* __restrict__ src, u8* __restrict__ dst,
-                                                    const u8* __restrict__ norm_lut, Geom g, int blocks_per_frame)
+                                                    const u8* __restrict__ norm_lut, const u32* __restrict__ minmax, size_t mm_stride,
+                                                    Geom g, int blocks_per_frame)
 {
     __shared__ u8 lut[256];
-    lut[threadIdx.x] = norm_lut[(size_t)blockIdx.z * 256 + threadIdx.x];
+    if (minmax) { // NormSrc::minmax: the table from the frame's extremes, worked out by every workgroup
+        const u32* mm = minmax + (size_t)blockIdx.z * mm_stride;
+        lut[threadIdx.x] = d_norm_lut_entry((int)mm[0], (int)mm[1], (int)threadIdx.x);
+    } else lut[threadIdx.x] = norm_lut[(size_t)blockIdx.z * 256 + threadIdx.x];
     __syncthreads();
     const size_t fo = (size_t)blockIdx.z * g.frame_stride;
     const int wb = g.w * 3;
@@ -1106,14 +1111,14 @@ __global__ __launch_bounds__(256) void k_normalize(const u8* __restrict__ src, u
     }
 }
 
-int launch_normalize(cbv_ctx* ctx, const u8* src, u8* dst, const u8* norm_lut, Geom g, int batch)
+int launch_normalize(cbv_ctx* ctx, const u8* src, u8* dst, NormSrc norm, Geom g, int batch)
 {
     size_t nvec = (size_t)g.w * 3 * g.h / 16;
     int blocks = (int)((nvec + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     prof_begin(ctx, CBV_K_NORMALIZE);
-    hipLaunchKernelGGL(k_normalize, dim3(blocks, 1, batch), dim3(256), 0, ctx->stream, src, dst, norm_lut, g, blocks);
+    hipLaunchKernelGGL(k_normalize, dim3(blocks, 1, batch), dim3(256), 0, ctx->stream, src, dst, norm.lut, norm.minmax, norm.mm_stride, g, blocks);
     prof_end(ctx, CBV_K_NORMALIZE);
     CBV_HIP(ctx, hipGetLastError());
     return CBV_OK;

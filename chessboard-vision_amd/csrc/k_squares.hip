@@ -710,16 +710,24 @@ __global__ __launch_bounds__(64) void k_scan(const SquareDesc* __restrict__ desc
 }
 
 // per-square flag bytes of a frame -> the eight 64-bit square sets of cbv_frame_result
-__global__ void k_pack_results(const u8* __restrict__ flags, int n, cbv_frame_result* __restrict__ results, int count)
+// `mirror` (may be null): the same records written to pinned host memory as well, and `over_src` (HoughCircles' overflow
+// counter) copied to `over_dst` there, so that reading results back is a wait and a host copy, not two more launches
+// (ResultMirror).
+__global__ void k_pack_results(const u8* __restrict__ flags, int n, cbv_frame_result* __restrict__ results, int count, ResultMirror mir)
 {
+    if (mir.over_dst && blockIdx.x == 0 && threadIdx.x == 0) *mir.over_dst = mir.over_src ? *mir.over_src : 0u;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6), sq = threadIdx.x & 63;
     if (t >= count) return;
     const u32 fl = sq < n ? flags[(size_t)t * CBV_MAX_SQUARES + sq] : 0u;
     u64* r = (u64*)&results[t];
+    u64* hm = mir.records ? (u64*)&mir.records[t] : nullptr;
 #pragma unroll
     for (int b = 0; b < 8; b++) {
         const u64 m = __ballot((fl >> b) & 1u);
-        if (sq == 0) r[b] = m;
+        if (sq == 0) {
+            r[b] = m;
+            if (hm) hm[b] = m;
+        }
     }
 }
 
@@ -797,16 +805,21 @@ __global__ void k_noise(const u64* __restrict__ changes, size_t stride_words, in
 // k_pack_results + k_noise of a run of at most four frames (one workgroup packs them all) in ONE launch: on a run of
 // one frame every launch in the chain is ~4.5 us of latency
 __global__ __launch_bounds__(256) void k_pack_noise(const u8* __restrict__ flags, int n, cbv_frame_result* __restrict__ results, int count,
-                                                     cbv_noise_state* __restrict__ state, cbv_noise_result* __restrict__ out)
+                                                     cbv_noise_state* __restrict__ state, cbv_noise_result* __restrict__ out, ResultMirror mir)
 {
+    if (mir.over_dst && threadIdx.x == 0) *mir.over_dst = mir.over_src ? *mir.over_src : 0u;
     const int t = threadIdx.x >> 6, sq = threadIdx.x & 63;
     if (t < count) {
         const u32 fl = sq < n ? flags[(size_t)t * CBV_MAX_SQUARES + sq] : 0u;
         u64* r = (u64*)&results[t];
+        u64* hm = mir.records ? (u64*)&mir.records[t] : nullptr;
 #pragma unroll
         for (int b = 0; b < 8; b++) {
             const u64 m = __ballot((fl >> b) & 1u);
-            if (sq == 0) r[b] = m;
+            if (sq == 0) {
+                r[b] = m;
+                if (hm) hm[b] = m;
+            }
         }
     }
     __threadfence_block();
@@ -823,16 +836,16 @@ int launch_noise(cbv_ctx* ctx, const u64* changes, size_t stride_words, int coun
 
 int launch_scan(cbv_ctx* ctx, const SquareDesc* descs, ScanParams sp, const u8* gray, size_t gray_frame_stride,
                 const u8* decisions, u8* ref, ScanState* state, u8* flags, cbv_frame_result* results, int count,
-                const u64* check, cbv_noise_state* noise_state, cbv_noise_result* noise_out)
+                const u64* check, cbv_noise_state* noise_state, cbv_noise_result* noise_out, ResultMirror mir)
 {
     // noise_state != null: NoiseHandler over the frames' visual_changes sets follows the scan (game_session.py:165)
     prof_begin(ctx, CBV_K_SCAN);
     hipLaunchKernelGGL(k_scan, dim3(sp.n), dim3(64), 0, ctx->stream, descs, sp, gray, gray_frame_stride, decisions, ref,
                        state, flags, count, check);
     if (noise_state && count <= 4)
-        hipLaunchKernelGGL(k_pack_noise, dim3(1), dim3(256), 0, ctx->stream, flags, sp.n, results, count, noise_state, noise_out);
+        hipLaunchKernelGGL(k_pack_noise, dim3(1), dim3(256), 0, ctx->stream, flags, sp.n, results, count, noise_state, noise_out, mir);
     else
-        hipLaunchKernelGGL(k_pack_results, dim3((count + 3) / 4), dim3(256), 0, ctx->stream, flags, sp.n, results, count);
+        hipLaunchKernelGGL(k_pack_results, dim3((count + 3) / 4), dim3(256), 0, ctx->stream, flags, sp.n, results, count, mir);
     prof_end(ctx, CBV_K_SCAN);
     CBV_HIP(ctx, hipGetLastError());
     if (noise_state && count > 4)

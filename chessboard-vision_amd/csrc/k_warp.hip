@@ -18,20 +18,31 @@ struct WarpM {
 // FPT frames per thread: the coordinates of a destination pixel depend on the matrix and the pixel, not on the frame, and
 // they are most of the kernel's instructions (about 100 of 190 per output pixel, in double precision): a thread works
 // them out once and samples FPT consecutive frames of the batch with them (blockIdx.z counts groups of FPT frames).
-template <int FPT>
+// CALC: the byte map is worked out here from the frames' [min, max] words (NormSrc::minmax) instead of read from a table.
+template <int FPT, bool CALC>
 __global__ __launch_bounds__(256) void k_warp(const u8* __restrict__ src, Geom g, WarpM M, int dw, int dh, int bw0,
                                                int bh0, int rot180, u8* __restrict__ dst, int dst_stride,
-                                               size_t dst_frame_stride, const u8* __restrict__ norm_lut, u32* __restrict__ zero_word,
-                                               int batch)
+                                               size_t dst_frame_stride, const u8* __restrict__ norm_lut, const u32* __restrict__ minmax,
+                                               size_t mm_stride, u32* __restrict__ zero_word, u32* __restrict__ zero_word2, int batch)
 {
     __shared__ u8 lut[FPT][256];
     // the pipeline's HoughCircles worklist counter, filled by the NEXT kernel in the stream (k_squares_pre5_stats):
     // zeroed here instead of by a 4-byte memset, which is one more ~4.5 us launch in a single-frame run
-    if (zero_word && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) *zero_word = 0u;
-    const bool use_lut = norm_lut != nullptr;
+    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+        if (zero_word) *zero_word = 0u;
+        if (zero_word2) *zero_word2 = 0u; // the run's second-pass list, when this launch is the run's only chunk
+    }
+    const bool use_lut = CALC || norm_lut != nullptr;
     const int f0 = blockIdx.z * FPT;
     const int nf = min(FPT, batch - f0);
-    if (use_lut)
+    if (CALC) {
+#pragma unroll
+        for (int k = 0; k < FPT; k++)
+            if (k < nf) {
+                const u32* mm = minmax + (size_t)(f0 + k) * mm_stride;
+                lut[k][threadIdx.x] = d_norm_lut_entry((int)mm[0], (int)mm[1], (int)threadIdx.x);
+            }
+    } else if (use_lut)
 #pragma unroll
         for (int k = 0; k < FPT; k++)
             if (k < nf) lut[k][threadIdx.x] = norm_lut[(size_t)(f0 + k) * 256 + threadIdx.x];
@@ -115,7 +126,7 @@ __global__ __launch_bounds__(256) void k_warp(const u8* __restrict__ src, Geom g
 }
 
 int launch_warp(cbv_ctx* ctx, const u8* src, Geom g, const double* Minv9, int dw, int dh, int rot180, u8* dst,
-                int dst_stride, size_t dst_frame_stride, const u8* norm_lut, int batch, u32* zero_word)
+                int dst_stride, size_t dst_frame_stride, NormSrc norm, int batch, u32* zero_word, u32* zero_word2)
 {
     WarpM M;
     for (int i = 0; i < 9; i++) M.m[i] = Minv9[i];
@@ -128,12 +139,20 @@ int launch_warp(cbv_ctx* ctx, const u8* src, Geom g, const double* Minv9, int dw
     // a frame or two keeps one thread per pixel and frame
     if (batch >= 8) {
         dim3 grid((dw + 63) / 64, (dh + 3) / 4, (batch + 3) / 4);
-        hipLaunchKernelGGL(k_warp<4>, grid, dim3(256), 0, ctx->stream, src, g, M, dw, dh, bw0, bh0, rot180, dst, dst_stride,
-                           dst_frame_stride, norm_lut, zero_word, batch);
+        if (norm.minmax)
+            hipLaunchKernelGGL((k_warp<4, true>), grid, dim3(256), 0, ctx->stream, src, g, M, dw, dh, bw0, bh0, rot180, dst, dst_stride,
+                               dst_frame_stride, nullptr, norm.minmax, norm.mm_stride, zero_word, zero_word2, batch);
+        else
+            hipLaunchKernelGGL((k_warp<4, false>), grid, dim3(256), 0, ctx->stream, src, g, M, dw, dh, bw0, bh0, rot180, dst, dst_stride,
+                               dst_frame_stride, norm.lut, nullptr, 0, zero_word, zero_word2, batch);
     } else {
         dim3 grid((dw + 63) / 64, (dh + 3) / 4, batch);
-        hipLaunchKernelGGL(k_warp<1>, grid, dim3(256), 0, ctx->stream, src, g, M, dw, dh, bw0, bh0, rot180, dst, dst_stride,
-                           dst_frame_stride, norm_lut, zero_word, batch);
+        if (norm.minmax)
+            hipLaunchKernelGGL((k_warp<1, true>), grid, dim3(256), 0, ctx->stream, src, g, M, dw, dh, bw0, bh0, rot180, dst, dst_stride,
+                               dst_frame_stride, nullptr, norm.minmax, norm.mm_stride, zero_word, zero_word2, batch);
+        else
+            hipLaunchKernelGGL((k_warp<1, false>), grid, dim3(256), 0, ctx->stream, src, g, M, dw, dh, bw0, bh0, rot180, dst, dst_stride,
+                               dst_frame_stride, norm.lut, nullptr, 0, zero_word, zero_word2, batch);
     }
     prof_end(ctx, CBV_K_WARP);
     CBV_HIP(ctx, hipGetLastError());

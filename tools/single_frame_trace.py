@@ -40,8 +40,10 @@ def show(path):
         name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name))
     rows.sort()
-    # the last frame: from the last k_reset_aux (first kernel of the chain) on
-    start = max(i for i, x in enumerate(rows) if x[2] == "k_reset_aux")
+    # the last frame: from the last k_color_lab_hist (first kernel of the chain) on, with a reset / fill launch right before it
+    start = max(i for i, x in enumerate(rows) if x[2] == "k_color_lab_hist")
+    while start > 0 and rows[start][0] - rows[start - 1][1] < 40000 and ("fillBuffer" in rows[start - 1][2] or rows[start - 1][2] == "k_reset_aux"):
+        start -= 1
     rows = rows[start:]
     t0 = rows[0][0]
     busy = 0
