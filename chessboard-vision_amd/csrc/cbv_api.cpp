@@ -1499,8 +1499,9 @@ struct cbv_pipeline {
     // ingest: pinned host mirror of the frame ring, filled by the capture side and copied on its own stream
     u8* host_ring = nullptr;
     u8* h_stage = nullptr; // pinned mirror of d_results ([max_frames] records, then the HoughCircles overflow word): written by
-                           // every run's last kernel (ResultMirror), read by cbv_pipeline_results after a wait
+                           // the last kernel of a SHORT run (ResultMirror), by a copy otherwise; read by cbv_pipeline_results
     size_t h_stage_bytes = 0;
+    std::vector<u8> slot_mirrored; // per slot: the mirror holds the slot's newest record (once its run has finished)
     hipStream_t copy_stream = nullptr;
     struct CopyRec {
         int s0, cnt;
@@ -1748,6 +1749,7 @@ extern "C" int cbv_pipeline_configure(cbv_pipeline* p, const cbv_pipeline_config
             p->h_stage_bytes = want;
         }
         memset(p->h_stage, 0, p->h_stage_bytes);
+        p->slot_mirrored.assign((size_t)p->max_frames, 0);
     }
     RC(dev_ensure(ctx, &p->d_flags, (size_t)CBV_MAX_SQUARES * p->max_frames));
     RC(dev_ensure(ctx, &p->d_dec, (size_t)CBV_MAX_SQUARES * p->max_frames));
@@ -1963,10 +1965,18 @@ static int pipeline_run_tail(cbv_pipeline* p, cbv_pipeline::RunRec* rec, int slo
             if ((double)sum / (double)len >= cfg.min_presence) sp.stable_table |= 1ull << (len * 8 + sum);
     sp.thr_is_int = (cfg.change_threshold == (double)(int)cfg.change_threshold && cfg.change_threshold >= 0 && cfg.change_threshold < 256) ? 1 : 0;
     sp.thr_int = (int)cfg.change_threshold;
+    // A short run (the live-camera case) writes its records to the pinned mirror too: reading them back is then a wait and a
+    // host copy instead of two more launches.  Not the long runs: their records would cross PCIe as thousands of 8-byte
+    // writes inside the scan stream's critical path (512-frame steps: -0.5 % frames/s, alternating A/B runs); they are
+    // fetched with one copy when asked for.
     ResultMirror mir;
-    mir.records = (cbv_frame_result*)p->h_stage + slot0;
-    mir.over_src = cfg.use_hough ? (const u32*)p->d_hough_over.p : nullptr;
-    mir.over_dst = pipeline_over_word(p);
+    const bool mirrored = count <= 4;
+    if (mirrored) {
+        mir.records = (cbv_frame_result*)p->h_stage + slot0;
+        mir.over_src = cfg.use_hough ? (const u32*)p->d_hough_over.p : nullptr;
+        mir.over_dst = pipeline_over_word(p);
+    }
+    for (int t = 0; t < count; t++) p->slot_mirrored[(size_t)slot0 + t] = mirrored ? 1 : 0;
     // + NoiseHandler on the frames' visual_changes sets (game_session.py:165)
     RC(launch_scan(ctx, (const SquareDesc*)p->d_descs.p, sp, (const u8*)p->d_gray.p + p->plane_total * slot0, p->plane_total,
                    (const u8*)p->d_dec.p + (size_t)CBV_MAX_SQUARES * slot0, (u8*)p->d_ref.p, (ScanState*)p->d_state.p,
@@ -2116,11 +2126,21 @@ extern "C" int cbv_pipeline_results(cbv_pipeline* p, int slot0, int count, cbv_f
     CBV_ENTER(ctx);
     RC(join_scan(p)); // lanes and scan of the last run
     if (!p->configured || !p->h_stage) return cbv_fail(ctx, CBV_ERR_STATE, "cbv_pipeline_results: the pipeline is not configured");
-    // the records are already in pinned host memory (ResultMirror): wait for the runs, copy on the host
+    // short runs left their records in pinned host memory (ResultMirror): wait for the runs, copy on the host; the others
+    // are fetched into the same place first (through pinned memory in any case: a copy into the caller's pageable buffer
+    // would be staged by the runtime, one blocking copy at a time)
     const size_t bytes = sizeof(cbv_frame_result) * (size_t)count;
-    CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    memcpy(out, (const cbv_frame_result*)p->h_stage + slot0, bytes);
     u32* over_h = pipeline_over_word(p);
+    bool have = true;
+    for (int t = 0; t < count; t++) have = have && p->slot_mirrored[(size_t)slot0 + t];
+    if (!have) {
+        CBV_HIP(ctx, hipMemcpyAsync((cbv_frame_result*)p->h_stage + slot0, (cbv_frame_result*)p->d_results.p + slot0, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        if (p->cfg.use_hough && p->d_hough_over.p) CBV_HIP(ctx, hipMemcpyAsync(over_h, p->d_hough_over.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!have)
+        for (int t = 0; t < count; t++) p->slot_mirrored[(size_t)slot0 + t] = 1;
+    memcpy(out, (const cbv_frame_result*)p->h_stage + slot0, bytes);
     const u32 over = *over_h;
     if (over) {
         // A truncated candidate list may change has_piece: never hand that over as if it were HoughCircles' answer.  The
