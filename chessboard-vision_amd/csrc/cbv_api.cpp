@@ -1249,7 +1249,7 @@ struct FastLayout {
 };
 static int fast_layout(cbv_squares* s, FastLayout* L)
 {
-    const size_t o_retry = 512, o_out = 1024;
+    const size_t o_retry = 512, o_out = 1024; // (cbv_squares_detect_all copies [retry, out + out_bytes) back as one block)
     // the block is copied back to offset 8192 of the 64 KB pinned staging area, whose tail (from 40960) holds the host-built worklist
     static_assert(8192 + 64 + (2 * sizeof(cbv_sq_stats) + sizeof(cbv_hough_result)) * CBV_MAX_SQUARES <= 40960, "result block overruns the staging area");
     static_assert(sizeof(SquareDesc) * CBV_MAX_SQUARES <= 8192 && 40960 + 4 * (1 + CBV_MAX_SQUARES) <= 65536, "staging layout");
@@ -1301,9 +1301,16 @@ extern "C" int cbv_squares_detect_all(cbv_squares* s, const cbv_host_image* img,
     RC(launch_squares_pre5_stats(ctx, (const u8*)s->d_stage.p, 0, (const SquareDesc*)s->d_descs.p, n, (u8*)s->d_gray.p, 0, nullptr, nullptr,
                                  (const u8*)s->d_masks.p, 0.f, L.stats, 1, nullptr, 1, L.work, L.hough, max_px_of(s), (const u8*)s->d_ref.p, &dm));
     RC(launch_hough(ctx, (const SquareDesc*)s->d_descs.p, n, (const u8*)s->d_gray.p, 0, hc, L.hough, nullptr, L.work, 1, L.retry, 0));
-    RC(launch_hough_second(ctx, (const SquareDesc*)s->d_descs.p, n, (const u8*)s->d_gray.p, 0, hc, L.hough, nullptr, L.retry, n));
-    CBV_HIP(ctx, hipMemcpyAsync(hst + o_back, L.out, L.out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    // the second-pass list travels back in front of the results (it sits 512 bytes before them): normally it is empty
+    // and the second pass, a launch of its own, is never enqueued
+    const size_t o_retry_back = o_back - 512;
+    CBV_HIP(ctx, hipMemcpyAsync(hst + o_retry_back, L.retry, 512 + L.out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (*(const u32*)(hst + o_retry_back) != 0) {
+        RC(launch_hough_second(ctx, (const SquareDesc*)s->d_descs.p, n, (const u8*)s->d_gray.p, 0, hc, L.hough, nullptr, L.retry, n));
+        CBV_HIP(ctx, hipMemcpyAsync(hst + o_back + L.o_hough, L.hough, sizeof(cbv_hough_result) * CBV_MAX_SQUARES, hipMemcpyDeviceToHost, ctx->stream));
+        CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     const cbv_sq_stats* st = (const cbv_sq_stats*)(hst + o_back + L.o_stats);
     const cbv_hough_result* hg = (const cbv_hough_result*)(hst + o_back + L.o_hough);
     const u8* fl = hst + o_back + L.o_flags;
@@ -1391,9 +1398,15 @@ extern "C" int cbv_squares_detect_changes(cbv_squares* s, const cbv_host_image* 
         CBV_HIP(ctx, hipMemsetAsync(L.retry, 0, sizeof(u32), ctx->stream));
         const u8* g5 = five ? (const u8*)s->d_gray.p : (const u8*)s->d_gray5.p;
         RC(launch_hough(ctx, (const SquareDesc*)s->d_descs.p, n, g5, 0, hc, L.hough, nullptr, L.work, 1, L.retry, 0));
-        RC(launch_hough_second(ctx, (const SquareDesc*)s->d_descs.p, n, g5, 0, hc, L.hough, nullptr, L.retry, n));
+        u32* retry_back = (u32*)(hst + o_wk + 1024);
+        CBV_HIP(ctx, hipMemcpyAsync(retry_back, L.retry, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
         CBV_HIP(ctx, hipMemcpyAsync(hst + o_back + L.o_hough, L.hough, sizeof(cbv_hough_result) * n, hipMemcpyDeviceToHost, ctx->stream));
         CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (*retry_back != 0) { // (normally empty: the second pass is a launch of its own)
+            RC(launch_hough_second(ctx, (const SquareDesc*)s->d_descs.p, n, g5, 0, hc, L.hough, nullptr, L.retry, n));
+            CBV_HIP(ctx, hipMemcpyAsync(hst + o_back + L.o_hough, L.hough, sizeof(cbv_hough_result) * n, hipMemcpyDeviceToHost, ctx->stream));
+            CBV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
         hg = (const cbv_hough_result*)(hst + o_back + L.o_hough);
     }
     for (int i = 0; i < n; i++) {

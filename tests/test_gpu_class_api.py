@@ -364,3 +364,39 @@ def test_planes_written_by_the_host_take_effect(gpu_ctx, oracle):
     cd.update_all_references(b)
     ref.update_all_references(b)
     assert cd.detect_changes_detailed(a) == ref.detect_changes_detailed(a)
+
+
+def test_one_call_paths_take_the_second_hough_pass_when_a_square_needs_it(gpu_ctx, oracle):
+    """White-noise squares hold more accumulator maxima than HoughCircles' first pass keeps; the one-call entry points
+    read the second-pass list back with the results and launch the second pass only when it is not empty.  Both cases,
+    for detect_all_pieces and detect_changes_detailed, against the restated reference logic."""
+    from chessboard_vision_amd import _native as N
+    from chessboard_vision_amd._squares import SquareSet
+    from chessboard_vision_amd.change_detector import ChangeDetector
+    from chessboard_vision_amd.grid_extractor import GridExtractor
+    from chessboard_vision_amd.piece_detector import PieceDetector
+    from ref_logic import RefChangeDetector, RefPieceDetector
+    rng = np.random.default_rng(11)
+    ge = GridExtractor()
+    calm = np.full((620, 620, 3), 120, np.uint8)
+    calm += rng.integers(0, 4, calm.shape, dtype=np.uint8)
+    noisy = calm.copy()
+    patterns = [rng.integers(0, 2, (77, 77), dtype=np.uint8) * 255, rng.integers(0, 256, (77, 77), dtype=np.uint8),
+                rng.integers(0, 2, (77, 77), dtype=np.uint8) * 200 + 20]
+    for (c, r), pat in zip(((1, 1), (5, 2), (6, 6)), patterns):  # three squares of noise, the rest of the board calm
+        noisy[r * 77:(r + 1) * 77, c * 77:(c + 1) * 77] = pat[:, :, None]
+    # with an accumulator threshold of 15 the noise squares really overflow the first pass (else this test exercises nothing)
+    probe = SquareSet()
+    probe.load(ge.split_board(noisy), 5)
+    assert sum(h.n_centres > 512 for h in probe.hough(param2=15)) >= 2, [h.n_centres for h in probe.hough(param2=15)]
+    det, ref = PieceDetector(), RefPieceDetector(hough={"param2": 15})
+    cd, cref = ChangeDetector(), RefChangeDetector(hough={"param2": 15})
+    det.hough_param2 = cd.piece_detector.hough_param2 = 15
+    cd.calibrate(ge.split_board(calm))
+    cref.calibrate(ge.split_board(calm))
+    for board in (calm, noisy, calm, noisy):
+        sq = ge.split_board(board)
+        r, v = det.detect_all_pieces(sq)
+        r_ref, v_ref = ref.detect_all_pieces(sq)
+        assert v == v_ref and r == r_ref
+        assert cd.detect_changes_detailed(sq) == cref.detect_changes_detailed(sq)
