@@ -420,7 +420,7 @@ def main():
                     "i %% N with its own pipeline, the frames a GPU holds are split evenly over its streams")
     ap.add_argument("--no-noise-leg", action="store_true", help="skip the white-noise scene leg")
     ap.add_argument("--no-class-api", action="store_true", help="skip the class-API (one host frame per call) leg")
-    ap.add_argument("--splits", type=int, default=2, help="a step's frames are enqueued as this many consecutive runs "
+    ap.add_argument("--splits", type=int, default=4, help="a step's frames are enqueued as this many consecutive runs "
                     "(the temporal scan of one run overlaps the enhancement of the next)")
     args = ap.parse_args()
     if args.gpus < 1:
